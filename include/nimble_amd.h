@@ -1,0 +1,143 @@
+/* nimble_amd.h — C-ABI of the MI355X pseudoalignment engine (libnimble_amd.so).
+ *
+ * Drop-in boundary. In the reference the hot path is entered through ONE process boundary:
+ *   subprocess.Popen([<pkgdir>/aligner] + argv); proc.wait()      /root/reference/nimble/__main__.py:195-198
+ * with argv = --input F.. -c N --strand_filter S {-r LIB -o OUT}.. [-t TRIM]   (__main__.py:177-192)
+ * and the exit code as the only status (__main__.py:198,211). The reference has no FFI for this path
+ * (ctypes is imported at __main__.py:5 only for csv.field_size_limit, :374), so the entry points below are what a
+ * ctypes binding placed at __main__.py:195 binds instead of spawning the Rust binary; INTEGRATION.md shows it.
+ *
+ * Conventions: plain C, no C++/torch types. Every function returns int32 status (0 = NB_OK, <0 = error) unless
+ * stated; nb_last_error() returns a thread-local message for the last failing call on this thread. Host buffers are
+ * caller-allocated. Device memory of the index and of the class table is owned by the library behind the opaque
+ * handles; read batches and per-read outputs are caller-provided DEVICE pointers (e.g. torch tensors' data_ptr) and
+ * `stream` is a hipStream_t passed as void* (NULL = default stream). One nb_ctx per host thread / GPU; no globals.
+ */
+#ifndef NIMBLE_AMD_H
+#define NIMBLE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_OK 0
+#define NB_ERR_INVALID (-1)     /* bad argument */
+#define NB_ERR_HIP (-2)         /* a HIP runtime call failed (message has the hipError string) */
+#define NB_ERR_UNSUPPORTED (-3) /* valid request this build cannot serve (e.g. read longer than NB_MAX_READ_LEN) */
+#define NB_ERR_OVERFLOW (-4)    /* class table full: raise max_classes */
+#define NB_ERR_NOGPU (-5)       /* no usable HIP device */
+
+#define NB_ABI_VERSION 1
+#define NB_MAX_K 31
+#define NB_MAX_POSITIONS 320    /* k-mer positions per read the kernels handle (5 wave-rounds of 64) */
+#define NB_NO_CLASS 0xFFFFFFFFu
+
+/* strand_filter values; strings accepted by the CLI at /root/reference/nimble/__main__.py:399 */
+#define NB_STRAND_UNSTRANDED 0
+#define NB_STRAND_FIVEPRIME 1
+#define NB_STRAND_THREEPRIME 2
+#define NB_STRAND_NONE 3
+
+/* reason codes, docs/SPEC.md §4 */
+enum {
+  NB_CALLED = 0, NB_TOO_SHORT = 1, NB_NO_HIT = 2, NB_SCORE_THRESHOLD = 3, NB_SCORE_PERCENT = 4, NB_EMPTY_EQCLASS = 5,
+  NB_MULTIPLE_MATCH = 6, NB_INVALID_PAIR = 7, NB_STRAND = 8, NB_SCORE_FILTER = 9, NB_MAX_HITS = 10, NB_MULTI_HITS = 11,
+  NB_NUM_REASONS = 12
+};
+
+/* Aligner parameters evaluated on the device. Replaces the numeric part of the library JSON's config object that
+ * the Rust binary parses: /root/reference/nimble/types.py:10-25 (field for field where named the same).
+ * group_on / discard_multi_hits / max_hits_to_report act on feature NAMES and stay on the host (nimble_amd/align.py). */
+typedef struct nb_config {
+  int32_t k;                        /* k-mer length, 2..31; docs/SPEC.md §1 (default 20) */
+  int32_t score_threshold;          /* types.py:12 */
+  int32_t score_filter;             /* types.py:13 */
+  int32_t num_mismatches;           /* types.py:15 */
+  int32_t discard_multiple_matches; /* types.py:16 (bool) */
+  int32_t intersect_level;          /* types.py:17: 0 union, 1 intersect with fallback, 2 force intersect */
+  int32_t require_valid_pair;       /* types.py:20 (bool) */
+  int32_t strand_filter;            /* NB_STRAND_*; --strand_filter, __main__.py:180,399 */
+  double score_percent;             /* types.py:14 */
+} nb_config;
+
+typedef struct nb_index_stats_t {
+  int64_t n_seqs;
+  int64_t n_kmers;        /* distinct stranded k-mers (|S|) */
+  int64_t n_canonical;    /* occupied slots of the canonical-k-mer table */
+  int64_t table_slots;    /* capacity (power of two), 16 B each */
+  int64_t n_colours;      /* equivalence classes of the graph */
+  int64_t words_per_row;  /* u64 words per colour bitset = ceil(n_seqs/64) */
+  int64_t device_bytes;   /* bytes the index occupies in HBM once uploaded */
+  int32_t k;
+  int32_t uploaded;
+} nb_index_stats_t;
+
+typedef struct nb_ctx nb_ctx;
+typedef struct nb_index nb_index;
+
+int32_t nb_version(void);
+const char* nb_last_error(void);
+
+/* ---- context: one per GPU. max_classes bounds the number of distinct result sets (class table capacity). ---- */
+int32_t nb_ctx_create(int32_t device_id, int64_t max_classes, nb_ctx** out);
+int32_t nb_ctx_destroy(nb_ctx* ctx);
+int32_t nb_ctx_sync(nb_ctx* ctx, void* stream);
+
+/* ---- index: replaces the Rust binary's "-r LIB" load + graph build (__main__.py:182-189).
+ * Built on the host from the library's `sequence` column (types.py:29-32, headers[3]); host-only, needs no GPU. ---- */
+int32_t nb_index_build(int32_t n_seqs, const char* const* seqs, const int64_t* seq_lens, int32_t k, nb_index** out);
+int32_t nb_index_destroy(nb_index* index);
+int32_t nb_index_stats(const nb_index* index, nb_index_stats_t* out);
+/* host query of one stranded k-mer (ASCII, length k): returns 1 if present and fills exts/flags/colour bitset
+ * (words_per_row u64), 0 if absent, <0 on error. Used by index-parity tests. */
+int32_t nb_index_query(const nb_index* index, const char* kmer_ascii, uint8_t* lext, uint8_t* rext, uint8_t* r_internal,
+                       uint8_t* l_internal, uint64_t* colour_bits);
+/* copy the index into HBM of ctx's GPU and bind it to ctx */
+int32_t nb_index_upload(nb_ctx* ctx, nb_index* index);
+
+/* ---- read packing (host helper): replaces the Rust binary's FASTQ/BAM record decode for the device format.
+ * Layout per read: bases_words = ceil(max_len/32) u64 of 2-bit codes (base i at bits [2*(i%32), +2) of word i/32,
+ * A C G T = 0 1 2 3, N packed as 0) followed by nmask_words = ceil(max_len/64) u64 with bit i set iff base i is N.
+ * stride (u64 words) = bases_words + nmask_words. `ascii` holds the reads back to back, read i = [off[i], off[i+1]). */
+int64_t nb_packed_stride_words(int32_t max_len);
+int32_t nb_pack_reads(const char* ascii, const int64_t* offsets, int64_t n_reads, int32_t max_len, uint64_t* out_words,
+                      uint16_t* out_lens);
+
+/* ---- the hot path: replaces the per-read work of the Rust binary (one call per batch, any number of batches).
+ * d_reads/d_lens (+ optional mates) are DEVICE pointers in the packed layout above; d_lens may be NULL when every
+ * read has length max_len. Outputs (device, caller-allocated, any may be NULL to skip):
+ *   d_out_class[n]  u32  class id (index into the ctx class table) or NB_NO_CLASS
+ *   d_out_info[n]   u32  bits 0-15 score, 16-23 reason, 24 orientation (0 = F, 1 = R), 25-26 mates
+ *   d_out_cov[n]    u64  four u16 coverage scores: r1 fwd | r1 rev << 16 | r2 fwd << 32 | r2 rev << 48
+ * Also accumulates count[class] += 1 per called template and per-reason counters in ctx. Asynchronous on `stream`. */
+int32_t nb_align_batch(nb_ctx* ctx, const nb_config* cfg, const uint64_t* d_reads, const uint16_t* d_lens, int32_t max_len,
+                       const uint64_t* d_mates, const uint16_t* d_mate_lens, int32_t mate_max_len, int64_t n_reads,
+                       uint32_t* d_out_class, uint32_t* d_out_info, uint64_t* d_out_cov, void* stream);
+
+/* ---- results held in ctx (synchronise the stream first) ---- */
+int32_t nb_classes_count(nb_ctx* ctx, int64_t* n_classes);
+/* rows_out: n_classes * words_per_row u64 (bitset over sequences); counts_out: n_classes i64 */
+int32_t nb_classes_read(nb_ctx* ctx, int64_t cap, uint64_t* rows_out, int64_t* counts_out);
+int32_t nb_reasons_read(nb_ctx* ctx, int64_t* counts_out /* NB_NUM_REASONS */);
+int32_t nb_results_reset(nb_ctx* ctx, void* stream);
+/* device pointer + length of the per-class count vector (u64), for an RCCL reduce by the caller (bench.py, align.py) */
+int32_t nb_counts_device_ptr(nb_ctx* ctx, void** d_counts, int64_t* capacity);
+
+/* ---- FASTQ(.gz) ingest (host): replaces the Rust binary's decode of each "--input" file (__main__.py:177-179) and,
+ * for 10x R1, the CB/UMI split of /root/reference/nimble/fastq_barcode_processor.py:131-141. Packs straight into the
+ * device layout. cb_out/umi_out (fixed width cb_len/umi_len per record) and out_words/out_lens may each be NULL. ---- */
+typedef struct nb_fastq nb_fastq;
+int32_t nb_fastq_open(const char* path, nb_fastq** out);
+int32_t nb_fastq_close(nb_fastq* fq);
+int32_t nb_fastq_next_batch(nb_fastq* fq, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
+                            int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len);
+
+/* name of the kernel nb_align_batch launches for this shape (for matching rocprofv3 kernel-trace rows) */
+const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIMBLE_AMD_H */

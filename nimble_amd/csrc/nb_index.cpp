@@ -1,0 +1,183 @@
+// nb_index.cpp — host-side build of the coloured k-mer index (product code; pure C++, no GPU needed).
+//
+// Replaces the graph build the Rust binary performs after parsing "-r LIB" (/root/reference/nimble/__main__.py:182-189)
+// from the library's `sequence` column (/root/reference/nimble/types.py:29-32). Semantics: docs/SPEC.md §2.
+// Sort-based (no hash maps): every stranded k-mer occurrence is emitted with its one-base left/right context, the
+// array is sorted, and colours / extension masks fall out of a single grouped pass. The result is the flat
+// canonical-k-mer table the kernels probe plus the colour bitset rows.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <unordered_map>
+
+#include "nb_internal.h"
+
+namespace nb {
+
+namespace {
+
+struct Occ {
+  uint64_t kmer;
+  uint32_t seq;
+  uint8_t lext, rext;  // single-bit masks (or 0) contributed by this occurrence
+};
+
+struct KRec {
+  uint64_t kmer;
+  uint32_t colour;  // temp id, later remapped
+  uint8_t lext, rext, r_int, l_int;
+};
+
+inline int code_of(char c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+
+inline uint64_t mix64(uint64_t z) {
+  z ^= z >> 33; z *= 0xff51afd7ed558ccdull; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull; z ^= z >> 33; return z;
+}
+
+const KRec* find_rec(const std::vector<KRec>& recs, uint64_t x) {
+  auto it = std::lower_bound(recs.begin(), recs.end(), x, [](const KRec& r, uint64_t v) { return r.kmer < v; });
+  return (it != recs.end() && it->kmer == x) ? &*it : nullptr;
+}
+
+}  // namespace
+
+int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, int k, HostIndex** out) {
+  if (n_seqs <= 0 || !seqs || !lens || !out) { set_error("nb_index_build: null or empty input"); return NB_ERR_INVALID; }
+  if (k < 2 || k > NB_MAX_K) { set_error("nb_index_build: k must be in 2..31"); return NB_ERR_INVALID; }
+  const uint64_t mask = kmer_mask(k);
+  const int top = 2 * (k - 1);
+
+  // 1. occurrences
+  int64_t total = 0;
+  for (int s = 0; s < n_seqs; ++s) total += std::max<int64_t>(0, lens[s] - k + 1);
+  std::vector<Occ> occ; occ.reserve((size_t)total);
+  for (int s = 0; s < n_seqs; ++s) {
+    const char* p = seqs[s]; const int64_t L = lens[s];
+    uint64_t x = 0; int64_t run = 0;
+    for (int64_t i = 0; i < L; ++i) {
+      const int c = code_of(p[i]);
+      if (c == 4) { run = 0; x = 0; continue; }
+      x = (x >> 2) | ((uint64_t)c << top); ++run;
+      if (run >= k) {
+        Occ o; o.kmer = x & mask; o.seq = (uint32_t)s; o.lext = 0; o.rext = 0;
+        if (run >= k + 1) o.lext = (uint8_t)(1u << code_of(p[i - k]));           // (K+1)-mer a·x occurs
+        if (i + 1 < L) { const int n = code_of(p[i + 1]); if (n != 4) o.rext = (uint8_t)(1u << n); }  // x·b occurs
+        occ.push_back(o);
+      }
+    }
+  }
+  if (occ.empty()) { set_error("nb_index_build: library has no k-mer of length k"); return NB_ERR_INVALID; }
+  std::sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) { return a.kmer != b.kmer ? a.kmer < b.kmer : a.seq < b.seq; });
+
+  // 2. group by k-mer: merged exts, member list; intern member lists into temp colour ids
+  std::vector<KRec> recs;
+  std::vector<uint32_t> pool;                 // concatenated member lists of distinct colours
+  std::vector<uint64_t> col_off{0};           // offsets into pool
+  std::unordered_multimap<uint64_t, uint32_t> by_hash;
+  std::vector<uint32_t> members;
+  for (size_t i = 0; i < occ.size();) {
+    size_t j = i; uint8_t le = 0, re = 0; members.clear();
+    while (j < occ.size() && occ[j].kmer == occ[i].kmer) {
+      le |= occ[j].lext; re |= occ[j].rext;
+      if (members.empty() || members.back() != occ[j].seq) members.push_back(occ[j].seq);
+      ++j;
+    }
+    uint64_t h = 0x1234567ull + members.size();
+    for (uint32_t m : members) h = mix64(h ^ (uint64_t)m);
+    uint32_t id = 0xFFFFFFFFu;
+    auto range = by_hash.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+      const uint32_t c = it->second; const uint64_t b = col_off[c], e = col_off[c + 1];
+      if (e - b == members.size() && std::equal(members.begin(), members.end(), pool.begin() + (std::ptrdiff_t)b)) { id = c; break; }
+    }
+    if (id == 0xFFFFFFFFu) {
+      id = (uint32_t)(col_off.size() - 1);
+      pool.insert(pool.end(), members.begin(), members.end());
+      col_off.push_back(pool.size());
+      by_hash.emplace(h, id);
+    }
+    recs.push_back(KRec{occ[i].kmer, id, le, re, 0, 0});
+    i = j;
+  }
+  std::vector<Occ>().swap(occ);
+  const uint32_t n_col = (uint32_t)(col_off.size() - 1);
+  if (n_col > MAX_COLOURS) { set_error("nb_index_build: more than 2^22-1 equivalence classes"); return NB_ERR_UNSUPPORTED; }
+
+  // 3. final colour ids: ascending set size, ties by member list (lexicographic). The kernels rely on
+  //    "smaller id = no larger set" to seed the intersection with the smallest class without a size lookup.
+  std::vector<uint32_t> order(n_col); std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    const uint64_t la = col_off[a + 1] - col_off[a], lb = col_off[b + 1] - col_off[b];
+    if (la != lb) return la < lb;
+    return std::lexicographical_compare(pool.begin() + (std::ptrdiff_t)col_off[a], pool.begin() + (std::ptrdiff_t)col_off[a + 1],
+                                        pool.begin() + (std::ptrdiff_t)col_off[b], pool.begin() + (std::ptrdiff_t)col_off[b + 1]);
+  });
+  std::vector<uint32_t> remap(n_col);
+  for (uint32_t r = 0; r < n_col; ++r) remap[order[r]] = r;
+  for (auto& r : recs) r.colour = remap[r.colour];
+
+  HostIndex* ix = new HostIndex();
+  ix->k = k; ix->n_seqs = n_seqs; ix->words = (n_seqs + 63) / 64; ix->n_kmers = (int64_t)recs.size();
+  ix->eq_rows.assign((size_t)n_col * (size_t)ix->words, 0ull);
+  ix->eq_sizes.resize(n_col);
+  for (uint32_t c = 0; c < n_col; ++c) {
+    const uint32_t id = remap[c];
+    ix->eq_sizes[id] = (uint32_t)(col_off[c + 1] - col_off[c]);
+    uint64_t* row = ix->eq_rows.data() + (size_t)id * (size_t)ix->words;
+    for (uint64_t t = col_off[c]; t < col_off[c + 1]; ++t) row[pool[t] >> 6] |= 1ull << (pool[t] & 63);
+  }
+
+  // 4. unitig-interior flags (SPEC §2, local rule). recs is sorted by k-mer.
+  for (auto& r : recs) {
+    if (__builtin_popcount(r.rext) == 1) {
+      const uint64_t y = (r.kmer >> 2) | ((uint64_t)__builtin_ctz(r.rext) << top);
+      const KRec* yr = find_rec(recs, y);
+      if (yr && __builtin_popcount(yr->lext) == 1 && yr->colour == r.colour && y != r.kmer) r.r_int = 1;
+    }
+  }
+  for (auto& r : recs) {
+    if (__builtin_popcount(r.lext) == 1) {
+      const uint64_t x = ((r.kmer << 2) | (uint64_t)__builtin_ctz(r.lext)) & mask;
+      const KRec* xr = find_rec(recs, x);
+      if (xr && xr->r_int) r.l_int = 1;
+    }
+  }
+
+  // 5. canonical table, linear probing, load factor <= 0.5
+  int cap_log2 = 10;
+  while ((1ull << cap_log2) < 2 * recs.size()) ++cap_log2;
+  ix->cap_log2 = cap_log2;
+  ix->slots.assign((size_t)1 << cap_log2, Slot{SLOT_EMPTY, {PAY_ABSENT, PAY_ABSENT}});
+  const uint64_t smask = ((uint64_t)1 << cap_log2) - 1;
+  int64_t n_canon = 0;
+  for (const auto& r : recs) {
+    const uint64_t y = rc_kmer_host(r.kmer, k);
+    const uint64_t canon = std::min(r.kmer, y);
+    const int o = (r.kmer != canon) ? 1 : 0;
+    const uint32_t pay = make_payload(r.colour, r.lext, r.rext, r.r_int, r.l_int);
+    uint64_t h = slot_of(canon, cap_log2);
+    for (;;) {
+      Slot& s = ix->slots[h];
+      if (s.key == SLOT_EMPTY) { s.key = canon; ++n_canon; }
+      if (s.key == canon) {
+        s.pay[o] = pay;
+        if (r.kmer == y) s.pay[1] = pay;  // palindrome: both orientations are this k-mer
+        break;
+      }
+      h = (h + 1) & smask;
+    }
+  }
+  ix->n_canonical = n_canon;
+  *out = ix;
+  return NB_OK;
+}
+
+}  // namespace nb

@@ -1,0 +1,717 @@
+// nb_kernels.hip — hand-written gfx950 kernels of the pseudoalignment hot path + the C-ABI that launches them.
+//
+// Replaces the per-read work of the Rust `nimble-aligner` binary spawned at /root/reference/nimble/__main__.py:195
+// (k-mer extraction, index lookup, equivalence-class intersection, scoring, filtering, counting). Semantics:
+// docs/SPEC.md. Formulation: ONE READ PER WAVE, ONE K-MER POSITION PER LANE.
+//   1. every lane extracts its k-mer from the 2-bit packed read, canonicalises it and probes the canonical-k-mer
+//      table once; the slot carries the payload of BOTH strands, so one probe serves read and reverse complement;
+//   2. wave ballots turn per-position facts into bit masks (hit, right-extendable, left-extendable);
+//   3. the SPEC §3 walk (stride-3 seeding, left extension, runs, re-seeding) becomes a handful of find-first-bit
+//      operations on those masks, executed uniformly by the wave;
+//   4. the colours of the visited positions are intersected: the smallest class row seeds an accumulator spread
+//      over the lanes (one u64 word per lane), then for each non-zero word every visited lane gathers its own
+//      class's word and a wave AND-reduction folds them;
+//   5. the result set is interned in a lock-free class table (64-bit content hash + full compare) and counted.
+// Integer/bit work only: no MFMA. Wave = 64 everywhere.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "nb_internal.h"
+
+namespace nb {
+
+// ------------------------------------------------------------------------------------------------------------
+// device-side views
+struct DevIndex {
+  const Slot* slots;
+  const uint64_t* eq;   // n_colours * W
+  int cap_log2;
+  int W;                // u64 words per colour row
+  int K;
+};
+
+struct DevClasses {
+  unsigned long long* keys;    // cap slots, 0 = free
+  unsigned int* ids;           // cap slots, id+1 once published, 0 = not yet, 0xFFFFFFFF = overflow
+  unsigned long long* rows;    // max_classes * W
+  unsigned long long* counts;  // max_classes
+  unsigned int* n_classes;     // allocated ids
+  unsigned int* err;           // bit0: class table overflow, bit1: spin timeout
+  unsigned long long* reasons; // NB_NUM_REASONS
+  unsigned int cap_log2;
+  unsigned int max_classes;
+};
+
+struct BatchArgs {
+  const uint64_t* reads; const uint16_t* lens; int max_len; int stride; int nwb;     // r1
+  const uint64_t* mates; const uint16_t* mate_lens; int mate_max_len; int mstride; int mnwb;  // r2 (optional)
+  long long n;
+  uint32_t* out_class; uint32_t* out_info; uint64_t* out_cov;
+  const uint16_t* pct_min;   // pct_min[L] = smallest cov with (double)cov/(double)L >= score_percent, L in 0..max(max_len,mate_max_len)
+  int score_threshold, score_filter, num_mismatches, discard_multiple, intersect_level, require_valid_pair, strand_filter;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// wave-level helpers (wave64)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_and_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+    v &= ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v) {  // lane 0's value to every lane
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z ^= z >> 33; z *= 0xff51afd7ed558ccdull; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull; z ^= z >> 33; return z;
+}
+
+// reverse complement of a k-mer held LSB-first (nb_internal.h encoding)
+__device__ __forceinline__ uint64_t rc_kmer(uint64_t x, int K) {
+  uint64_t v = __brevll(~x);
+  v = ((v & 0x5555555555555555ull) << 1) | ((v >> 1) & 0x5555555555555555ull);
+  return v >> (64 - 2 * K);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// multiword bit masks over k-mer positions (NR words, wave-uniform values)
+template <int NR> struct Mask { uint64_t w[NR]; };
+
+// first set bit at a position p >= from with (p - from) % 3 == 0, or -1          (SPEC §3 seed(), SCAN_STRIDE = 3)
+template <int NR> __device__ __forceinline__ int ffs_stride3(const Mask<NR>& m, int from) {
+  const uint64_t PAT = 0x9249249249249249ull;  // bits t with t % 3 == 0
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) {
+    const int base = wi * 64;
+    if (from < base + 64) {
+      uint64_t v = m.w[wi];
+      const int res = ((from % 3) - (wi % 3) + 3) % 3;  // want t with (base + t) % 3 == from % 3; 64 % 3 == 1
+      v &= PAT << res;
+      if (from > base) v &= ~0ull << (from - base);
+      if (v) return base + __builtin_ctzll(v);
+    }
+  }
+  return -1;
+}
+// first ZERO bit at a position >= from (caller guarantees one exists below NR*64)
+template <int NR> __device__ __forceinline__ int ffz_from(const Mask<NR>& m, int from) {
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) {
+    const int base = wi * 64;
+    if (from < base + 64) {
+      uint64_t v = ~m.w[wi];
+      if (from > base) v &= ~0ull << (from - base);
+      if (v) return base + __builtin_ctzll(v);
+    }
+  }
+  return NR * 64;
+}
+// highest ZERO bit at a position <= from (bit 0 of the masks passed here is always zero)
+template <int NR> __device__ __forceinline__ int flz_upto(const Mask<NR>& m, int from) {
+#pragma unroll
+  for (int wi = NR - 1; wi >= 0; --wi) {
+    const int base = wi * 64;
+    if (from >= base) {
+      uint64_t v = ~m.w[wi];
+      if (from < base + 63) v &= (2ull << (from - base)) - 1;
+      if (v) return base + 63 - __builtin_clzll(v);
+    }
+  }
+  return 0;
+}
+template <int NR> __device__ __forceinline__ void set_range(Mask<NR>& m, int lo, int hi) {  // inclusive, lo <= hi
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) {
+    const int base = wi * 64;
+    if (lo < base + 64 && hi >= base) {
+      const int a = lo > base ? lo - base : 0, b = hi < base + 63 ? hi - base : 63;
+      const uint64_t hi_mask = (b == 63) ? ~0ull : ((2ull << b) - 1);
+      m.w[wi] |= hi_mask & (~0ull << a);
+    }
+  }
+}
+// out bit j = in bit (P-1-j), j in [0,P)
+template <int NR> __device__ __forceinline__ Mask<NR> reverse_mask(const Mask<NR>& in, int P) {
+  uint64_t t[NR + 1];
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) t[wi] = __brevll(in.w[NR - 1 - wi]);   // full reversal over NR*64 bits
+  t[NR] = 0;
+  const int S = NR * 64 - P, ws = S >> 6, bs = S & 63;                    // then shift right by S
+  Mask<NR> out;
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) {
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int s = 0; s <= NR; ++s) {
+      if (s == wi + ws) lo = t[s];
+      if (s == wi + ws + 1) hi = t[s];
+    }
+    out.w[wi] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+  }
+  return out;
+}
+template <int NR> __device__ __forceinline__ bool any_set(const Mask<NR>& m) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) v |= m.w[wi];
+  return v != 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// SPEC §3 on masks, exact mode (no tolerated mismatch). H = k-mer present, R = present and the next read base is a
+// right extension, LX = present and the previous read base is a left extension. Positions are in walk order
+// (position 0 = first k-mer of the sequence being mapped). Returns coverage (0 = NONE) and the visited positions.
+template <int NR>
+__device__ __forceinline__ int walk_masks(const Mask<NR>& H, const Mask<NR>& R, const Mask<NR>& LX, int L, int K, Mask<NR>& V) {
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) V.w[wi] = 0;
+  const int last = L - K;
+  int p = ffs_stride3<NR>(H, 0);
+  if (p < 0) return 0;
+  int cov = 0;
+  if (p >= L / 5 && p > 0) {               // left extension: consecutive LX bits going down from p
+    const int z = flz_upto<NR>(LX, p);
+    const int t = p - z;
+    if (t > 0) { cov += t; set_range<NR>(V, p - t, p - 1); }
+  }
+  for (;;) {
+    const int e = ffz_from<NR>(R, p);      // run p..e
+    cov += K + (e - p);
+    set_range<NR>(V, p, e);
+    const int b = e + K;
+    if (b > last) break;
+    p = ffs_stride3<NR>(H, b);
+    if (p < 0) break;
+  }
+  return cov;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-lane facts of one k-mer position for both strands
+struct PosFacts {
+  uint32_t payF, payR;   // payload for the read strand / for the reverse-complement strand (PAY_ABSENT if none)
+  bool hF, rF, lF, hR, rR, lR;
+};
+
+__device__ __forceinline__ PosFacts position_facts(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int i, bool active) {
+  PosFacts f; f.payF = PAY_ABSENT; f.payR = PAY_ABSENT; f.hF = f.rF = f.lF = f.hR = f.rR = f.lR = false;
+  if (!active) return f;
+  const int K = ix.K;
+  const uint64_t* np = rp + nwb;
+  // window of 32 bases starting at base i, and the N bits of bases i..i+K
+  const int wi = i >> 5, sh = (i & 31) * 2;
+  const uint64_t lo = rp[wi], hi = (wi + 1 < nwb) ? rp[wi + 1] : 0ull;
+  const uint64_t win = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+  const int nwi = i >> 6, nsh = i & 63, nwn = (nwb + 1) >> 1;
+  const uint64_t nlo = np[nwi], nhi = (nwi + 1 < nwn) ? np[nwi + 1] : 0ull;
+  const uint64_t nwin = nsh ? ((nlo >> nsh) | (nhi << (64 - nsh))) : nlo;
+  const bool validk = (nwin & ((1ull << K) - 1)) == 0;
+  if (!validk) return f;
+  const uint64_t x = win & ((1ull << (2 * K)) - 1);
+  const bool next_ok = (i + K < L) && !((nwin >> K) & 1);
+  const uint32_t nextb = (uint32_t)(win >> (2 * K)) & 3u;       // K <= 31 keeps this inside the 64-bit window
+  bool prev_ok = false; uint32_t prevb = 0;
+  if (i >= 1) {
+    const int j = i - 1;
+    prevb = (uint32_t)(rp[j >> 5] >> ((j & 31) * 2)) & 3u;
+    prev_ok = !((np[j >> 6] >> (j & 63)) & 1);
+  }
+  const uint64_t y = rc_kmer(x, K);
+  const uint64_t canon = x < y ? x : y;
+  const int o = (x != canon) ? 1 : 0;
+  const uint64_t smask = (1ull << ix.cap_log2) - 1;
+  uint64_t h = (canon * HASH_MULT) >> (64 - ix.cap_log2);
+  for (;;) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(&ix.slots[h]);
+    const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
+    if (key == canon) { f.payF = o ? raw.w : raw.z; f.payR = o ? raw.z : raw.w; break; }
+    if (key == SLOT_EMPTY) break;
+    h = (h + 1) & smask;
+  }
+  if (f.payF != PAY_ABSENT) {
+    f.hF = true;
+    f.rF = next_ok && ((f.payF >> nextb) & 1u);
+    f.lF = prev_ok && ((f.payF >> (4 + prevb)) & 1u);
+  }
+  if (f.payR != PAY_ABSENT) {           // rc strand: its next base is comp(prev), its previous base is comp(next)
+    f.hR = true;
+    f.rR = prev_ok && ((f.payR >> (3u - prevb)) & 1u);
+    f.lR = next_ok && ((f.payR >> (4 + (3u - nextb))) & 1u);
+  }
+  return f;
+}
+
+// One mapped strand of one sequence: coverage and the visited positions with their colours (lane-resident).
+template <int NR> struct Strand {
+  int cov;             // 0 = NONE
+  Mask<NR> V;          // visited positions, in read-position (lane) order
+  uint32_t col[NR];    // this lane's colour at position lane + 64 r on this strand
+};
+
+// Steps 1-3 for one sequence: facts for every position, ballots, both walks.
+template <int NR>
+__device__ __forceinline__ void map_both_strands(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int lane,
+                                                 Strand<NR>& F, Strand<NR>& R) {
+  const int K = ix.K, P = L - K + 1;
+  Mask<NR> HF, RF, LF, HR, RR, LR;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = lane + 64 * r;
+    const PosFacts f = position_facts(ix, rp, nwb, L, i, i < P);
+    F.col[r] = f.payF >> 10; R.col[r] = f.payR >> 10;
+    HF.w[r] = __ballot(f.hF); RF.w[r] = __ballot(f.rF); LF.w[r] = __ballot(f.lF);
+    HR.w[r] = __ballot(f.hR); RR.w[r] = __ballot(f.rR); LR.w[r] = __ballot(f.lR);
+  }
+  F.cov = any_set<NR>(HF) ? walk_masks<NR>(HF, RF, LF, L, K, F.V) : 0;
+  if (any_set<NR>(HR)) {
+    // rc strand position j is read position P-1-j: reverse the masks into walk order, walk, reverse the result back
+    const Mask<NR> h = reverse_mask<NR>(HR, P), r = reverse_mask<NR>(RR, P), l = reverse_mask<NR>(LR, P);
+    Mask<NR> v;
+    R.cov = walk_masks<NR>(h, r, l, L, K, v);
+    R.V = reverse_mask<NR>(v, P);
+  } else {
+    R.cov = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) R.V.w[r] = 0;
+  }
+}
+
+// Step 4: eq = AND of the colour rows of the visited positions. acc[t] (lane l) = word l + 64 t. Returns |eq|.
+template <int NR, int TW>
+__device__ __forceinline__ uint32_t intersect_visited(const DevIndex& ix, const Strand<NR>& S, int lane, uint64_t (&acc)[TW]) {
+  const int W = ix.W;
+  uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) if ((S.V.w[r] >> lane) & 1) mine = S.col[r] < mine ? S.col[r] : mine;
+  const uint32_t seed = wave_min_u32(mine);   // smallest id = smallest class (ids ascend by set size)
+#pragma unroll
+  for (int t = 0; t < TW; ++t) { const int w = lane + 64 * t; acc[t] = (w < W) ? ix.eq[(size_t)seed * W + w] : 0ull; }
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    uint64_t z = __ballot(acc[t] != 0);
+    while (z) {
+      const int wl = __builtin_ctzll(z); z &= z - 1;
+      const int wi = 64 * t + wl;
+      uint64_t v = ~0ull;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) if ((S.V.w[r] >> lane) & 1) v &= ix.eq[(size_t)S.col[r] * W + wi];
+      v = wave_and_u64(v);
+      if (lane == wl) acc[t] = v;
+    }
+  }
+  uint32_t n = 0;
+#pragma unroll
+  for (int t = 0; t < TW; ++t) n += (uint32_t)__popcll(acc[t]);
+  return wave_sum_u32(n);
+}
+
+// Step 5: intern the set held in acc (lane-distributed) and return its dense class id, or NB_NO_CLASS on overflow.
+template <int TW>
+__device__ __forceinline__ uint32_t intern_class(const DevClasses& ct, int W, int lane, const uint64_t (&acc)[TW]) {
+  uint64_t hsum = 0;
+#pragma unroll
+  for (int t = 0; t < TW; ++t) if (acc[t]) hsum += mix64(acc[t] ^ (0x9E3779B97F4A7C15ull * (uint64_t)(64 * t + lane + 1)));
+  uint64_t key = wave_sum_u64(hsum);
+  if (key == 0) key = 1;
+  const uint64_t smask = (1ull << ct.cap_log2) - 1;
+  uint64_t h = (key * HASH_MULT) >> (64 - ct.cap_log2);
+  for (uint64_t probes = 0; probes <= smask; ++probes, h = (h + 1) & smask) {
+    uint64_t cur = 0;
+    if (lane == 0) cur = __hip_atomic_load(&ct.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cur = bcast_u64(cur);
+    if (cur == 0) {
+      if (lane == 0) { unsigned long long expected = 0ull;
+        __hip_atomic_compare_exchange_strong(&ct.keys[h], &expected, (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur = expected; }
+      cur = bcast_u64(cur);
+      if (cur == 0) {   // this wave owns the slot: allocate an id, publish the row, then the id
+        uint32_t id = 0;
+        if (lane == 0) id = __hip_atomic_fetch_add(ct.n_classes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        id = __builtin_amdgcn_readfirstlane(id);
+        if (id >= ct.max_classes) {
+          if (lane == 0) { atomicOr(ct.err, 1u); __hip_atomic_store(&ct.ids[h], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          return NB_NO_CLASS;
+        }
+#pragma unroll
+        for (int t = 0; t < TW; ++t) { const int w = lane + 64 * t;
+          if (w < W) __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&ct.ids[h], id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return id;
+      }
+    }
+    if (cur == key) {
+      uint32_t idp = 0;
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (lane == 0) idp = __hip_atomic_load(&ct.ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idp = __builtin_amdgcn_readfirstlane(idp);
+        if (idp != 0) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (idp == 0) { if (lane == 0) atomicOr(ct.err, 2u); return NB_NO_CLASS; }
+      if (idp == 0xFFFFFFFFu) return NB_NO_CLASS;
+      const uint32_t id = idp - 1u;
+      bool diff = false;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) { const int w = lane + 64 * t;
+        if (w < W) diff |= (__hip_atomic_load(&ct.rows[(size_t)id * W + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != acc[t]); }
+      if (__ballot(diff) == 0) return id;
+      // genuine 64-bit hash collision between two different sets: keep probing
+    }
+  }
+  if (lane == 0) atomicOr(ct.err, 1u);
+  return NB_NO_CLASS;
+}
+
+// SPEC §4 checks 1-2 on a mapped strand (cheap part): returns 0 if it may be valid, else the reason.
+__device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) {
+  if (cov == 0) return NB_NO_HIT;
+  if (cov < a.score_threshold) return NB_SCORE_THRESHOLD;
+  if (cov < (int)a.pct_min[L]) return NB_SCORE_PERCENT;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// single-end kernel: one read per wave, grid-stride over the batch.
+template <int NR, int TW>
+__global__ __launch_bounds__(256) void nb_align_se_kernel(DevIndex ix, DevClasses ct, BatchArgs a) {
+  __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave; r < a.n; r += nwaves) {
+    int L = a.lens ? (int)a.lens[r] : a.max_len;
+    if (L > a.max_len) L = a.max_len;   // never index past the packed record
+    int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0; uint32_t cls = NB_NO_CLASS; int covF = 0, covR = 0;
+    if (L >= ix.K) {
+      const uint64_t* rp = a.reads + (size_t)r * a.stride;
+      Strand<NR> SF, SR;
+      map_both_strands<NR>(ix, rp, a.nwb, L, lane, SF, SR);
+      covF = SF.cov; covR = SR.cov;
+      // candidates in preference order: larger coverage first, tie -> F   (SPEC §4 "Chosen orientation")
+      const bool first_is_R = covR > covF;
+      int reasons[2]; uint64_t acc[TW]; bool called = false;
+#pragma unroll
+      for (int c = 0; c < 2 && !called; ++c) {
+        const bool isR = (c == 0) ? first_is_R : !first_is_R;
+        const int cov = isR ? covR : covF;
+        int rs = cheap_reason(cov, L, a);
+        if (rs == 0) {
+          const uint32_t n = isR ? intersect_visited<NR, TW>(ix, SR, lane, acc) : intersect_visited<NR, TW>(ix, SF, lane, acc);
+          if (n == 0) rs = NB_EMPTY_EQCLASS;
+          else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
+          else if ((isR && a.strand_filter == NB_STRAND_FIVEPRIME) || (!isR && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
+          else { called = true; orient = isR ? 1 : 0; score = cov; mates = 1; }
+        }
+        reasons[c] = rs;
+      }
+      if (called) {
+        if (score < a.score_filter) reason = NB_SCORE_FILTER;
+        else {
+          reason = NB_CALLED;
+          cls = intern_class<TW>(ct, ix.W, lane, acc);
+          if (cls != NB_NO_CLASS && lane == 0) atomicAdd(&ct.counts[cls], 1ull);
+        }
+      } else reason = reasons[0] > reasons[1] ? reasons[0] : reasons[1];
+    }
+    if (lane == 0) {
+      atomicAdd(&s_reason[reason], 1u);
+      if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
+      if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
+      if (a.out_cov) a.out_cov[r] = (uint64_t)(covF & 0xFFFF) | ((uint64_t)(covR & 0xFFFF) << 16);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side of the C-ABI
+thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+#define NB_HIP(call)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) { set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return NB_ERR_HIP; } \
+  } while (0)
+
+}  // namespace nb
+
+struct nb_index { nb::HostIndex* h; };
+
+struct nb_ctx {
+  int device = 0;
+  int n_cu = 256;
+  // bound index (device copies)
+  nb::Slot* d_slots = nullptr; uint64_t* d_eq = nullptr; int cap_log2 = 0, W = 0, K = 0, n_seqs = 0; int64_t index_bytes = 0;
+  // class table
+  nb::DevClasses ct{}; int64_t max_classes = 0;
+  // score_percent table
+  uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0;
+};
+
+using namespace nb;
+
+static int ensure_pct_table(nb_ctx* c, double score_percent, int max_len, hipStream_t stream) {
+  if (c->d_pct && c->pct_value == score_percent && c->pct_len >= max_len + 1) return NB_OK;
+  (void)hipFree(c->d_pct); c->d_pct = nullptr;
+  std::vector<uint16_t> t((size_t)max_len + 1, 0);
+  for (int L = 1; L <= max_len; ++L) {   // smallest cov with (double)cov/(double)L >= score_percent   (SPEC §4.2)
+    int cov = 0; while (cov <= 65534 && (double)cov / (double)L < score_percent) ++cov;
+    t[(size_t)L] = (uint16_t)cov;
+  }
+  NB_HIP(hipMalloc((void**)&c->d_pct, t.size() * 2));
+  NB_HIP(hipMemcpyAsync(c->d_pct, t.data(), t.size() * 2, hipMemcpyHostToDevice, stream));
+  NB_HIP(hipStreamSynchronize(stream));
+  c->pct_len = max_len + 1; c->pct_value = score_percent; return NB_OK;
+}
+
+template <int NR, int TW>
+static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
+  const long long waves_needed = a.n;
+  long long blocks = (waves_needed + 3) / 4;
+  const long long cap = (long long)c->n_cu * 8;   // 8 blocks of 4 waves per CU = 32 waves/CU
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
+  NB_HIP(hipGetLastError());
+  return NB_OK;
+}
+
+template <int TW>
+static int dispatch_se(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
+  switch (nr) {
+    case 1: return launch_se<1, TW>(c, ix, a, s);
+    case 2: return launch_se<2, TW>(c, ix, a, s);
+    case 3: return launch_se<3, TW>(c, ix, a, s);
+    case 4: return launch_se<4, TW>(c, ix, a, s);
+    default: return launch_se<5, TW>(c, ix, a, s);
+  }
+}
+
+extern "C" {
+
+int32_t nb_version(void) { return NB_ABI_VERSION; }
+const char* nb_last_error(void) { return g_err.c_str(); }
+
+int32_t nb_ctx_create(int32_t device_id, int64_t max_classes, nb_ctx** out) {
+  if (!out || max_classes < 1 || max_classes > (1ll << 28)) { set_error("nb_ctx_create: bad arguments"); return NB_ERR_INVALID; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { set_error("nb_ctx_create: no HIP device (this library has no CPU fallback)"); return NB_ERR_NOGPU; }
+  if (device_id < 0 || device_id >= n) { set_error("nb_ctx_create: device_id out of range"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(device_id));
+  nb_ctx* c = new nb_ctx(); c->device = device_id; c->max_classes = max_classes;
+  hipDeviceProp_t prop; NB_HIP(hipGetDeviceProperties(&prop, device_id)); c->n_cu = prop.multiProcessorCount;
+  c->ct.max_classes = (unsigned int)max_classes;
+  unsigned int cl = 10; while ((1ull << cl) < 2ull * (uint64_t)max_classes) ++cl; c->ct.cap_log2 = cl;
+  const size_t cap = (size_t)1 << cl;
+  NB_HIP(hipMalloc((void**)&c->ct.keys, cap * 8)); NB_HIP(hipMalloc((void**)&c->ct.ids, cap * 4));
+  NB_HIP(hipMalloc((void**)&c->ct.counts, (size_t)max_classes * 8));
+  NB_HIP(hipMalloc((void**)&c->ct.n_classes, 4)); NB_HIP(hipMalloc((void**)&c->ct.err, 4));
+  NB_HIP(hipMalloc((void**)&c->ct.reasons, NB_NUM_REASONS * 8));
+  NB_HIP(hipMemset(c->ct.keys, 0, cap * 8)); NB_HIP(hipMemset(c->ct.ids, 0, cap * 4));
+  NB_HIP(hipMemset(c->ct.counts, 0, (size_t)max_classes * 8));
+  NB_HIP(hipMemset(c->ct.n_classes, 0, 4)); NB_HIP(hipMemset(c->ct.err, 0, 4)); NB_HIP(hipMemset(c->ct.reasons, 0, NB_NUM_REASONS * 8));
+  c->ct.rows = nullptr;  // sized at index upload (needs W)
+  *out = c; return NB_OK;
+}
+
+int32_t nb_ctx_destroy(nb_ctx* c) {
+  if (!c) return NB_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(c->d_slots); (void)hipFree(c->d_eq); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct);
+  delete c; return NB_OK;
+}
+
+int32_t nb_ctx_sync(nb_ctx* c, void* stream) {
+  if (!c) { set_error("nb_ctx_sync: null ctx"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device)); NB_HIP(hipStreamSynchronize((hipStream_t)stream)); return NB_OK;
+}
+
+int32_t nb_index_build(int32_t n_seqs, const char* const* seqs, const int64_t* seq_lens, int32_t k, nb_index** out) {
+  if (!out) { set_error("nb_index_build: null out"); return NB_ERR_INVALID; }
+  HostIndex* h = nullptr;
+  const int rc = build_host_index(n_seqs, seqs, seq_lens, k, &h);
+  if (rc != NB_OK) return rc;
+  *out = new nb_index{h}; return NB_OK;
+}
+int32_t nb_index_destroy(nb_index* ix) { if (ix) { delete ix->h; delete ix; } return NB_OK; }
+
+int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
+  if (!ix || !s) { set_error("nb_index_stats: null argument"); return NB_ERR_INVALID; }
+  const HostIndex& h = *ix->h;
+  s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = (int64_t)h.slots.size();
+  s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
+  s->device_bytes = (int64_t)(h.slots.size() * sizeof(Slot) + h.eq_rows.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
+  return NB_OK;
+}
+
+int32_t nb_index_query(const nb_index* ix, const char* kmer, uint8_t* lext, uint8_t* rext, uint8_t* r_int, uint8_t* l_int, uint64_t* bits) {
+  if (!ix || !kmer) { set_error("nb_index_query: null argument"); return NB_ERR_INVALID; }
+  const HostIndex& h = *ix->h; uint64_t x = 0;
+  for (int j = 0; j < h.k; ++j) {
+    int c; switch (kmer[j]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: return 0; }
+    x |= (uint64_t)c << (2 * j);
+  }
+  const uint64_t y = rc_kmer_host(x, h.k), canon = x < y ? x : y; const int o = (x != canon);
+  const uint64_t smask = h.slots.size() - 1; uint64_t s = slot_of(canon, h.cap_log2);
+  for (;;) {
+    const Slot& sl = h.slots[s];
+    if (sl.key == SLOT_EMPTY) return 0;
+    if (sl.key == canon) {
+      const uint32_t p = sl.pay[o]; if (p == PAY_ABSENT) return 0;
+      if (rext) *rext = p & 15; if (lext) *lext = (p >> 4) & 15; if (r_int) *r_int = (p >> 8) & 1; if (l_int) *l_int = (p >> 9) & 1;
+      if (bits) std::memcpy(bits, h.eq_rows.data() + (size_t)(p >> 10) * h.words, (size_t)h.words * 8);
+      return 1;
+    }
+    s = (s + 1) & smask;
+  }
+}
+
+int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
+  if (!c || !ix) { set_error("nb_index_upload: null argument"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  HostIndex& h = *ix->h;
+  (void)hipFree(c->d_slots); (void)hipFree(c->d_eq); (void)hipFree(c->ct.rows); c->d_slots = nullptr; c->d_eq = nullptr; c->ct.rows = nullptr;
+  NB_HIP(hipMalloc((void**)&c->d_slots, h.slots.size() * sizeof(Slot)));
+  NB_HIP(hipMalloc((void**)&c->d_eq, h.eq_rows.size() * 8));
+  NB_HIP(hipMemcpy(c->d_slots, h.slots.data(), h.slots.size() * sizeof(Slot), hipMemcpyHostToDevice));
+  NB_HIP(hipMemcpy(c->d_eq, h.eq_rows.data(), h.eq_rows.size() * 8, hipMemcpyHostToDevice));
+  NB_HIP(hipMalloc((void**)&c->ct.rows, (size_t)c->max_classes * (size_t)h.words * 8));
+  c->cap_log2 = h.cap_log2; c->W = h.words; c->K = h.k; c->n_seqs = h.n_seqs;
+  c->index_bytes = (int64_t)(h.slots.size() * sizeof(Slot) + h.eq_rows.size() * 8); h.uploaded = 1;
+  return nb_results_reset(c, nullptr);
+}
+
+int64_t nb_packed_stride_words(int32_t max_len) { return (int64_t)((max_len + 31) / 32 + (max_len + 63) / 64); }
+
+int32_t nb_pack_reads(const char* ascii, const int64_t* off, int64_t n, int32_t max_len, uint64_t* out, uint16_t* out_lens) {
+  if (!ascii || !off || !out || n < 0 || max_len < 1 || max_len > 65535) { set_error("nb_pack_reads: bad arguments"); return NB_ERR_INVALID; }
+  const int nwb = (max_len + 31) / 32; const int64_t stride = nb_packed_stride_words(max_len);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t L = off[i + 1] - off[i];
+    if (L < 0 || L > max_len) { set_error("nb_pack_reads: read longer than max_len"); return NB_ERR_INVALID; }
+    uint64_t* w = out + i * stride; std::memset(w, 0, (size_t)stride * 8);
+    const char* p = ascii + off[i];
+    for (int64_t j = 0; j < L; ++j) {
+      uint64_t c;
+      switch (p[j]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break;
+        default: c = 0; w[nwb + (j >> 6)] |= 1ull << (j & 63); }
+      w[j >> 5] |= c << ((j & 31) * 2);
+    }
+    if (out_lens) out_lens[i] = (uint16_t)L;
+  }
+  return NB_OK;
+}
+
+int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads, const uint16_t* d_lens, int32_t max_len,
+                       const uint64_t* d_mates, const uint16_t* d_mate_lens, int32_t mate_max_len, int64_t n,
+                       uint32_t* d_out_class, uint32_t* d_out_info, uint64_t* d_out_cov, void* stream) {
+  if (!c || !cfg || !d_reads || n < 0 || max_len < 1) { set_error("nb_align_batch: bad arguments"); return NB_ERR_INVALID; }
+  if (!c->d_slots) { set_error("nb_align_batch: no index uploaded to this ctx"); return NB_ERR_INVALID; }
+  if (cfg->k != c->K) { set_error("nb_align_batch: cfg.k differs from the uploaded index's k"); return NB_ERR_INVALID; }
+  if (cfg->strand_filter < 0 || cfg->strand_filter > 3 || cfg->intersect_level < 0 || cfg->intersect_level > 2) { set_error("nb_align_batch: bad strand_filter/intersect_level"); return NB_ERR_INVALID; }
+  if (cfg->num_mismatches != 0) { set_error("nb_align_batch: num_mismatches > 0 is not implemented on the device yet"); return NB_ERR_UNSUPPORTED; }
+  if (d_mates) { set_error("nb_align_batch: paired templates are not implemented on the device yet"); return NB_ERR_UNSUPPORTED; }
+  const int lmax = max_len > mate_max_len ? max_len : mate_max_len;
+  const int positions = lmax - c->K + 1;
+  if (positions > NB_MAX_POSITIONS) { set_error("nb_align_batch: read longer than NB_MAX_POSITIONS + k - 1"); return NB_ERR_UNSUPPORTED; }
+  if (c->W > 64 * 4) { set_error("nb_align_batch: more than 16384 reference sequences"); return NB_ERR_UNSUPPORTED; }
+  if (n == 0) return NB_OK;
+  NB_HIP(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ensure_pct_table(c, cfg->score_percent, lmax, s); if (rc != NB_OK) return rc;
+  DevIndex ix{c->d_slots, c->d_eq, c->cap_log2, c->W, c->K};
+  BatchArgs a{};
+  a.reads = d_reads; a.lens = d_lens; a.max_len = max_len; a.stride = (int)nb_packed_stride_words(max_len); a.nwb = (max_len + 31) / 32;
+  a.mates = d_mates; a.mate_lens = d_mate_lens; a.mate_max_len = mate_max_len;
+  a.mstride = mate_max_len > 0 ? (int)nb_packed_stride_words(mate_max_len) : 0; a.mnwb = (mate_max_len + 31) / 32;
+  a.n = n; a.out_class = d_out_class; a.out_info = d_out_info; a.out_cov = d_out_cov; a.pct_min = c->d_pct;
+  a.score_threshold = cfg->score_threshold; a.score_filter = cfg->score_filter; a.num_mismatches = cfg->num_mismatches;
+  a.discard_multiple = cfg->discard_multiple_matches; a.intersect_level = cfg->intersect_level;
+  a.require_valid_pair = cfg->require_valid_pair; a.strand_filter = cfg->strand_filter;
+  const int nr = positions < 1 ? 1 : (positions + 63) / 64;
+  return (c->W <= 64) ? dispatch_se<1>(c, nr, ix, a, s) : dispatch_se<4>(c, nr, ix, a, s);
+}
+
+int32_t nb_classes_count(nb_ctx* c, int64_t* n) {
+  if (!c || !n) { set_error("nb_classes_count: null argument"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  unsigned int v = 0, e = 0;
+  NB_HIP(hipMemcpy(&v, c->ct.n_classes, 4, hipMemcpyDeviceToHost)); NB_HIP(hipMemcpy(&e, c->ct.err, 4, hipMemcpyDeviceToHost));
+  if (e & 2u) { set_error("class table: publish wait timed out"); return NB_ERR_HIP; }
+  if ((e & 1u) || v > (unsigned int)c->max_classes) { set_error("class table overflow: raise max_classes"); return NB_ERR_OVERFLOW; }
+  *n = (int64_t)v; return NB_OK;
+}
+
+int32_t nb_classes_read(nb_ctx* c, int64_t cap, uint64_t* rows, int64_t* counts) {
+  int64_t n = 0; const int rc = nb_classes_count(c, &n); if (rc != NB_OK) return rc;
+  if (cap < n) { set_error("nb_classes_read: cap smaller than the number of classes"); return NB_ERR_INVALID; }
+  if (n == 0) return NB_OK;
+  if (rows) NB_HIP(hipMemcpy(rows, c->ct.rows, (size_t)n * (size_t)c->W * 8, hipMemcpyDeviceToHost));
+  if (counts) NB_HIP(hipMemcpy(counts, c->ct.counts, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return NB_OK;
+}
+
+int32_t nb_reasons_read(nb_ctx* c, int64_t* out) {
+  if (!c || !out) { set_error("nb_reasons_read: null argument"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  NB_HIP(hipMemcpy(out, c->ct.reasons, NB_NUM_REASONS * 8, hipMemcpyDeviceToHost)); return NB_OK;
+}
+
+int32_t nb_results_reset(nb_ctx* c, void* stream) {
+  if (!c) { set_error("nb_results_reset: null ctx"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream; const size_t cap = (size_t)1 << c->ct.cap_log2;
+  NB_HIP(hipMemsetAsync(c->ct.keys, 0, cap * 8, s)); NB_HIP(hipMemsetAsync(c->ct.ids, 0, cap * 4, s));
+  NB_HIP(hipMemsetAsync(c->ct.counts, 0, (size_t)c->max_classes * 8, s));
+  NB_HIP(hipMemsetAsync(c->ct.n_classes, 0, 4, s)); NB_HIP(hipMemsetAsync(c->ct.err, 0, 4, s));
+  NB_HIP(hipMemsetAsync(c->ct.reasons, 0, NB_NUM_REASONS * 8, s));
+  return NB_OK;
+}
+
+int32_t nb_counts_device_ptr(nb_ctx* c, void** d_counts, int64_t* capacity) {
+  if (!c || !d_counts || !capacity) { set_error("nb_counts_device_ptr: null argument"); return NB_ERR_INVALID; }
+  *d_counts = c->ct.counts; *capacity = c->max_classes; return NB_OK;
+}
+
+const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired) {
+  static thread_local char buf[96];
+  const int positions = max_len - k + 1; const int nr = positions < 1 ? 1 : (positions + 63) / 64; const int W = (n_seqs + 63) / 64;
+  std::snprintf(buf, sizeof buf, "nb_align_%s_kernel<%d, %d>", paired ? "pe" : "se", nr > 5 ? 5 : nr, W <= 64 ? 1 : 4);
+  return buf;
+}
+
+}  // extern "C"

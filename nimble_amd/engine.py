@@ -1,0 +1,184 @@
+"""Thin Python objects over the C-ABI (include/nimble_amd.h). PyTorch is used only for device buffers and streams."""
+import ctypes as ct
+
+import numpy as np
+
+from . import _lib
+from ._lib import NbConfig, NbIndexStats, check
+
+STRAND_FILTERS = {"unstranded": 0, "fiveprime": 1, "threeprime": 2, "none": 3}
+
+REASONS = ["CALLED", "TOO_SHORT", "NO_HIT", "SCORE_THRESHOLD", "SCORE_PERCENT", "EMPTY_EQCLASS", "MULTIPLE_MATCH",
+           "INVALID_PAIR", "STRAND", "SCORE_FILTER", "MAX_HITS", "MULTI_HITS"]
+NO_CLASS = 0xFFFFFFFF
+DEFAULT_K = 20
+
+
+def make_config(k=DEFAULT_K, score_threshold=20, score_filter=25, score_percent=0.5, num_mismatches=0,
+                discard_multiple_matches=False, intersect_level=0, require_valid_pair=False, strand_filter="unstranded"):
+    """nb_config with the reference's defaults (/root/reference/nimble/types.py:12-20, __main__.py:399)."""
+    if isinstance(strand_filter, str):
+        if strand_filter not in STRAND_FILTERS:
+            raise ValueError(f"unknown strand_filter {strand_filter!r}; expected one of {sorted(STRAND_FILTERS)}")
+        strand_filter = STRAND_FILTERS[strand_filter]
+    return NbConfig(int(k), int(score_threshold), int(score_filter), int(num_mismatches), int(bool(discard_multiple_matches)),
+                    int(intersect_level), int(bool(require_valid_pair)), int(strand_filter), float(score_percent))
+
+
+def packed_stride_words(max_len):
+    return int(_lib.lib().nb_packed_stride_words(int(max_len)))
+
+
+def pack_reads(reads, max_len=None):
+    """Pack ASCII reads into the device layout. `reads` is a list of str/bytes. Returns (words[n, stride] u64, lens[n] u16)."""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    n = len(bs)
+    if max_len is None:
+        max_len = max((len(b) for b in bs), default=1) or 1
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(b) for b in bs], out=offs[1:])
+    blob = b"".join(bs)
+    stride = packed_stride_words(max_len)
+    words = np.zeros((n, stride), dtype=np.uint64)
+    lens = np.zeros(n, dtype=np.uint16)
+    check(_lib.lib().nb_pack_reads(blob, offs.ctypes.data_as(_lib.c_i64p), n, int(max_len),
+                                   words.ctypes.data_as(_lib.c_u64p), lens.ctypes.data_as(_lib.c_u16p)))
+    return words, lens
+
+
+class Index:
+    """Coloured k-mer index of one reference library (host build; docs/SPEC.md §2)."""
+
+    def __init__(self, sequences, k=DEFAULT_K):
+        seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in sequences]
+        self.n_seqs = len(seqs)
+        self.k = int(k)
+        arr = (ct.c_char_p * len(seqs))(*seqs)
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        h = ct.c_void_p()
+        check(_lib.lib().nb_index_build(len(seqs), arr, lens.ctypes.data_as(_lib.c_i64p), self.k, ct.byref(h)))
+        self._h = h
+
+    def stats(self):
+        s = NbIndexStats()
+        check(_lib.lib().nb_index_stats(self._h, ct.byref(s)))
+        return {f: getattr(s, f) for f, _ in NbIndexStats._fields_}
+
+    @property
+    def words(self):
+        return (self.n_seqs + 63) // 64
+
+    def query(self, kmer):
+        """Stranded k-mer lookup on the host copy: None or dict(lext, rext, r_internal, l_internal, members)."""
+        le, re, ri, li = ct.c_uint8(), ct.c_uint8(), ct.c_uint8(), ct.c_uint8()
+        bits = np.zeros(self.words, dtype=np.uint64)
+        rc = check(_lib.lib().nb_index_query(self._h, kmer.encode() if isinstance(kmer, str) else kmer, ct.byref(le), ct.byref(re),
+                                             ct.byref(ri), ct.byref(li), bits.ctypes.data_as(_lib.c_u64p)))
+        if rc == 0:
+            return None
+        return {"lext": le.value, "rext": re.value, "r_internal": ri.value, "l_internal": li.value, "members": bits_to_members(bits)}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().nb_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bits_to_members(row):
+    """u64 bitset row -> sorted list of sequence indices."""
+    row = np.ascontiguousarray(row, dtype=np.uint64)
+    bits = np.unpackbits(row.view(np.uint8), bitorder="little")
+    return np.nonzero(bits)[0].tolist()
+
+
+class Context:
+    """One GPU: holds the uploaded index and the class table; launches the alignment kernels."""
+
+    def __init__(self, device_id=0, max_classes=1 << 20):
+        h = ct.c_void_p()
+        check(_lib.lib().nb_ctx_create(int(device_id), int(max_classes), ct.byref(h)))
+        self._h = h
+        self.device_id = int(device_id)
+        self.index = None
+
+    def upload(self, index):
+        check(_lib.lib().nb_index_upload(self._h, index._h))
+        self.index = index
+
+    def align_batch(self, cfg, reads, lens, max_len, out_class=None, out_info=None, out_cov=None, mates=None, mate_lens=None,
+                    mate_max_len=0, stream=None, n=None):
+        """reads/lens/outputs are torch CUDA tensors (or None). Asynchronous on `stream` (torch stream or None = current)."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device_id)
+        sh = ct.c_void_p(stream.cuda_stream)
+        if n is None:
+            n = reads.shape[0]
+
+        def p(t):
+            return ct.c_void_p(t.data_ptr()) if t is not None else None
+        check(_lib.lib().nb_align_batch(self._h, ct.byref(cfg), p(reads), p(lens), int(max_len), p(mates), p(mate_lens),
+                                        int(mate_max_len), int(n), p(out_class), p(out_info), p(out_cov), sh))
+
+    def sync(self, stream=None):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device_id)
+        check(_lib.lib().nb_ctx_sync(self._h, ct.c_void_p(stream.cuda_stream)))
+
+    def classes(self):
+        """(rows[n_classes, W] u64, counts[n_classes] i64) in device id order."""
+        n = ct.c_int64()
+        check(_lib.lib().nb_classes_count(self._h, ct.byref(n)))
+        w = self.index.words
+        rows = np.zeros((n.value, w), dtype=np.uint64)
+        counts = np.zeros(n.value, dtype=np.int64)
+        if n.value:
+            check(_lib.lib().nb_classes_read(self._h, n.value, rows.ctypes.data_as(_lib.c_u64p), counts.ctypes.data_as(_lib.c_i64p)))
+        return rows, counts
+
+    def reasons(self):
+        out = np.zeros(len(REASONS), dtype=np.int64)
+        check(_lib.lib().nb_reasons_read(self._h, out.ctypes.data_as(_lib.c_i64p)))
+        return out
+
+    def reset(self, stream=None):
+        sh = None
+        if stream is not None:
+            sh = ct.c_void_p(stream.cuda_stream)
+        check(_lib.lib().nb_results_reset(self._h, sh))
+
+    def counts_device(self):
+        """(device pointer, capacity) of the u64 per-class count vector, for an RCCL reduce by the caller."""
+        ptr, cap = ct.c_void_p(), ct.c_int64()
+        check(_lib.lib().nb_counts_device_ptr(self._h, ct.byref(ptr), ct.byref(cap)))
+        return ptr.value, cap.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().nb_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_info(info):
+    """u32 info words -> dict of numpy arrays (score, reason, orientation, mates)."""
+    info = np.asarray(info, dtype=np.uint32)
+    return {"score": (info & 0xFFFF).astype(np.int32), "reason": ((info >> 16) & 0xFF).astype(np.uint8),
+            "orientation": ((info >> 24) & 1).astype(np.uint8), "mates": ((info >> 25) & 3).astype(np.uint8)}
+
+
+def decode_cov(cov):
+    cov = np.asarray(cov, dtype=np.uint64)
+    return np.stack([(cov >> np.uint64(16 * j)) & np.uint64(0xFFFF) for j in range(4)], axis=1).astype(np.int32)

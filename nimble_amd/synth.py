@@ -1,0 +1,77 @@
+"""Seeded synthetic HLA-like libraries and reads (SURVEY.md §8d recipe). No external data; numpy PCG64 only."""
+import numpy as np
+
+LIB_SEED = 20260109
+BASES = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+def synth_library(n_loci, alleles_per_locus, locus_len=1098, seed=LIB_SEED, min_rate=0.005, max_rate=0.03):
+    """Returns (names, seqs_codes list of uint8 arrays, lineage list). Each locus: random ancestor; alleles = ancestor with
+    i.i.d. substitutions at a per-allele rate drawn uniformly from [min_rate, max_rate]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    names, seqs, lineage = [], [], []
+    for locus in range(n_loci):
+        anc = rng.integers(0, 4, size=locus_len, dtype=np.uint8)
+        for a in range(alleles_per_locus):
+            rate = rng.uniform(min_rate, max_rate)
+            s = anc.copy()
+            hit = rng.random(locus_len) < rate
+            s[hit] = (s[hit] + rng.integers(1, 4, size=int(hit.sum()), dtype=np.uint8)) & 3
+            names.append(f"L{locus:03d}*{a + 1:03d}")
+            seqs.append(s)
+            lineage.append(f"L{locus:03d}")
+    return names, seqs, lineage
+
+
+def codes_to_str(codes):
+    return BASES[np.asarray(codes, dtype=np.uint8)].tobytes().decode()
+
+
+def synth_reads(seqs, n, read_len, seed, frac_random=0.10, err=0.01, n_rate=0.001):
+    """codes[n, read_len] uint8 (0..3, 4 = N): 90 % sampled from (allele, offset, strand) with substitution error,
+    10 % uniform random; 0.1 % of bases replaced by N."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    if (lens < read_len).any():
+        raise ValueError("reference sequence shorter than read_len")
+    offs = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    flat = np.concatenate(seqs).astype(np.uint8)
+    allele = rng.integers(0, len(seqs), size=n)
+    start = (rng.random(n) * (lens[allele] - read_len + 1)).astype(np.int64)
+    idx = (offs[allele] + start)[:, None] + np.arange(read_len, dtype=np.int64)[None, :]
+    reads = flat[idx]
+    rev = rng.random(n) < 0.5
+    reads[rev] = (3 - reads[rev])[:, ::-1]
+    sub = rng.random((n, read_len)) < err
+    reads[sub] = (reads[sub] + rng.integers(1, 4, size=int(sub.sum()), dtype=np.uint8)) & 3
+    rnd = rng.random(n) < frac_random
+    reads[rnd] = rng.integers(0, 4, size=(int(rnd.sum()), read_len), dtype=np.uint8)
+    reads[rng.random((n, read_len)) < n_rate] = 4
+    return reads
+
+
+def pack_codes(codes):
+    """Vectorised twin of nb_pack_reads for fixed-length code arrays: codes[n, L] -> words[n, stride] uint64."""
+    codes = np.asarray(codes, dtype=np.uint8)
+    n, L = codes.shape
+    nwb, nwn = (L + 31) // 32, (L + 63) // 64
+    out = np.zeros((n, nwb + nwn), dtype=np.uint64)
+    isn = codes == 4
+    two = np.where(isn, 0, codes).astype(np.uint64)
+    pad = np.zeros((n, nwb * 32), dtype=np.uint64)
+    pad[:, :L] = two
+    sh = (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, None, :]
+    out[:, :nwb] = np.bitwise_or.reduce(pad.reshape(n, nwb, 32) << sh, axis=2)
+    npad = np.zeros((n, nwn * 64), dtype=np.uint64)
+    npad[:, :L] = isn
+    sh1 = np.arange(64, dtype=np.uint64)[None, None, :]
+    out[:, nwb:] = np.bitwise_or.reduce(npad.reshape(n, nwn, 64) << sh1, axis=2)
+    return out
+
+
+def reads_to_ascii(codes):
+    """codes[n, L] -> (blob bytes, offsets int64[n+1])."""
+    codes = np.asarray(codes, dtype=np.uint8)
+    n, L = codes.shape
+    return BASES[codes].tobytes(), np.arange(n + 1, dtype=np.int64) * L
