@@ -79,6 +79,12 @@ def lib():
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). nimble_amd has no CPU fallback for the alignment path.")
+        try:
+            # torch bundles its own libamdhip64.so.7; load it first so the dynamic loader binds this library to the
+            # SAME HIP runtime (two runtimes in one process cannot both own the GPU). Without torch, /opt/rocm's is used.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = ct.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the header and the library disagree
