@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py — M reads/s aligned on MI355X (BASELINE.json metric), reads resident in HBM.
+
+Workload (BASELINE config 2): 10 M synthetic 150-bp single-end reads vs a 1 000-sequence HLA-like library
+(20 loci x 50 alleles, SURVEY.md §8d recipe), per GPU. A "step" = one pass of the alignment kernel over the whole
+batch. N > 1: one process per GPU (torchrun), reads sharded (each rank its own seeded batch, weak scaling), index
+replicated, no collective while aligning; the timed region ends with the dictionary agreement + ONE RCCL all-reduce
+of the per-class count vector. Prints ONE JSON line on rank 0.
+
+roofline.achieved = algorithmic bytes per read (ceil(2L/8) + ceil(L/8) + 8 = 65 B at L = 150) x reads per
+launch / average kernel duration measured with HIP events on the launch stream. cpu_baseline = the C++ oracle
+(oracle/nb_oracle.cpp, "port": a restatement, NOT the Rust nimble-aligner, which is unobtainable offline) timed on
+rank 0's host cores on a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--loci", type=int, default=20)
+    ap.add_argument("--alleles", type=int, default=50)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-sample", type=int, default=20_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nimble_amd import distributed, engine, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- library + index (identical on every rank) ----
+    t0 = time.time()
+    names, seqs, _ = synth.synth_library(args.loci, args.alleles)
+    strs = [synth.codes_to_str(s) for s in seqs]
+    index = engine.Index(strs, args.k)
+    stats = index.stats()
+    ctx = engine.Context(local_rank, max_classes=1 << 20)
+    ctx.upload(index)
+    t_index = time.time() - t0
+
+    # ---- reads: generated on the GPU, seed 2 + rank (seed 2 for c2, 4 + rank for c4) ----
+    L, n = args.read_len, args.reads
+    seed = 2 if world == 1 else 4 + rank
+    n_keep = max(args.parity_sample, args.cpu_sample) if rank == 0 else 0
+    t0 = time.time()
+    res = synth.synth_reads_packed_torch(seqs, n, L, seed, dev, return_codes_of_first=min(n_keep, n))
+    d_reads, first_codes = res if n_keep else (res, None)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    out_class = torch.empty(n, dtype=torch.int32, device=dev)
+    out_info = torch.empty(n, dtype=torch.int32, device=dev)
+    cfg = engine.make_config(k=args.k)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ctx.align_batch(cfg, d_reads, None, L, out_class, out_info, None, stream=stream, n=n)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps (+ the end-of-job count reduce) ----
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    rows, counts = ctx.classes()
+    glob_rows, glob_counts = distributed.reduce_class_counts(rows, counts, device=dev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = [a.elapsed_time(b) for a, b in evs]
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_reads = n * world * args.steps
+    value = total_reads / elapsed / 1e6
+    bytes_per_read = (2 * L + 7) // 8 + (L + 7) // 8 + 8
+    avg_kernel_s = float(np.mean(kern_ms)) / 1e3
+    achieved = bytes_per_read * n / avg_kernel_s / 1e9
+    reasons = ctx.reasons()
+
+    # ---- parity spot check + CPU baseline (not timed above) ----
+    parity = None
+    cpu = None
+    if first_codes is not None:
+        from oracle import oracle
+        t0 = time.time()
+        oix = oracle.OracleIndex(strs, args.k)
+        t_oidx = time.time() - t0
+        ns = min(args.parity_sample, n)
+        if ns:
+            blob, off = synth.reads_to_ascii(first_codes[:ns])
+            ora = oix.align(cfg, blob, off, n_threads=os.cpu_count() or 1)
+            cls = out_class[:ns].cpu().numpy().view(np.uint32)
+            info = engine.decode_info(out_info[:ns].cpu().numpy().view(np.uint32))
+            sets = np.zeros((ns, index.words), dtype=np.uint64)
+            called = cls != engine.NO_CLASS
+            sets[called] = rows[cls[called]]
+            parity = bool((sets == ora["set_bits"]).all() and (info["score"] == ora["score"]).all()
+                          and (info["reason"] == ora["reason"]).all() and (info["orientation"] == ora["orientation"]).all())
+        if world == 1 and not args.no_cpu_baseline and args.cpu_sample:
+            nc = min(args.cpu_sample, n)
+            cores = os.cpu_count() or 1
+            blob, off = synth.reads_to_ascii(first_codes[:nc])
+            t0 = time.perf_counter()
+            oix.align(cfg, blob, off, n_threads=cores)
+            dt = time.perf_counter() - t0
+            cpu = {"value": nc / dt / 1e6, "unit": "M reads/s", "cores": cores, "kind": "port",
+                   "sample": f"first {nc} reads of the same batch, {dt:.1f} s wall, alignment only (oracle index build {t_oidx:.1f} s not counted); "
+                             "C++ restatement of docs/SPEC.md, not the Rust nimble-aligner"}
+
+    line = {
+        "metric": "M reads/s aligned (150bp, 1k-seq HLA lib)", "value": value, "unit": "M reads/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{n} x {L}bp single-end reads per GPU vs {len(strs)}-seq HLA-like library (BASELINE configs[1]), k={args.k}",
+                   "reads_per_gpu": n, "read_len": L, "n_seqs": len(strs), "k": args.k, "parallelism": f"reads sharded x{world}, index replicated"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                     "kernel": engine._lib.lib().nb_kernel_name(L, args.k, len(strs), 0).decode(), "kernel_ms_avg": avg_kernel_s * 1e3,
+                     "algorithmic_bytes_per_read": bytes_per_read},
+        "cpu_baseline": cpu,
+        "parity_sample_ok": parity,
+        "index": {"kmers": stats["n_kmers"], "colours": stats["n_colours"], "table_MB": stats["table_slots"] * 16 / 1e6,
+                  "device_MB": stats["device_bytes"] / 1e6, "build_s": t_index},
+        "classes": int(glob_rows.shape[0]), "called_frac": float(reasons[0] / max(1, reasons.sum())), "readgen_s": t_gen,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

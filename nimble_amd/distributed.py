@@ -1,0 +1,63 @@
+"""Multi-GPU reduce of the per-class count vector. One process per GPU, torch.distributed.
+
+Reads shard across ranks with the index replicated; there is no data-path collective while aligning. Class ids are
+assigned per rank in first-seen order, so the end-of-job reduce first agrees on the dictionary (an all-gather of each
+rank's class bitset rows, a few KB..MB), then sums ONE dense count vector indexed by the agreed ids with a single
+all-reduce (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests). Mirrors what the Rust binary's worker
+threads do when they merge their per-thread {feature set -> count} maps at the end of `align`
+(process boundary at /root/reference/nimble/__main__.py:195-198)."""
+import numpy as np
+
+
+def merge_dictionaries(rows_list):
+    """rows_list: list of [n_i, W] uint64 arrays. Returns the agreed dictionary: unique rows in lexicographic order."""
+    W = rows_list[0].shape[1] if rows_list else 0
+    allrows = np.concatenate([r.reshape(-1, W) for r in rows_list], axis=0) if rows_list else np.zeros((0, W), np.uint64)
+    if allrows.shape[0] == 0:
+        return allrows
+    return np.unique(allrows, axis=0)
+
+
+def _row_keys(rows):
+    return [r.tobytes() for r in np.ascontiguousarray(rows)]
+
+
+def reduce_class_counts(rows, counts, device=None, group=None):
+    """rows [n, W] uint64 / counts [n] int64 of THIS rank -> (global_rows [G, W], global_counts [G]) on every rank.
+
+    With no initialised process group (single GPU) this is the identity up to the canonical row order."""
+    import torch
+    import torch.distributed as dist
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    W = rows.shape[1]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        glob = merge_dictionaries([rows])
+        pos = {k: i for i, k in enumerate(_row_keys(glob))}
+        out = np.zeros(glob.shape[0], dtype=np.int64)
+        for k, c in zip(_row_keys(rows), counts):
+            out[pos[k]] += c
+        return glob, out
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    # 1. dictionary agreement: sizes, then padded rows
+    n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    nmax = max(max(sizes), 1)
+    pad = torch.zeros((nmax, max(W, 1)), dtype=torch.int64, device=dev)
+    if rows.shape[0]:
+        pad[:rows.shape[0], :W] = torch.from_numpy(rows.view(np.int64)).to(dev)
+    gathered = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(gathered, pad, group=group)
+    parts = [g[:s, :W].cpu().numpy().view(np.uint64) for g, s in zip(gathered, sizes)]
+    glob = merge_dictionaries(parts)
+    # 2. ONE all-reduce of the dense per-class count vector
+    pos = {k: i for i, k in enumerate(_row_keys(glob))}
+    dense = np.zeros(max(glob.shape[0], 1), dtype=np.int64)
+    for k, c in zip(_row_keys(rows), counts):
+        dense[pos[k]] += c
+    t = torch.from_numpy(dense).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return glob, t.cpu().numpy()[:glob.shape[0]]

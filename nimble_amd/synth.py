@@ -75,3 +75,46 @@ def reads_to_ascii(codes):
     codes = np.asarray(codes, dtype=np.uint8)
     n, L = codes.shape
     return BASES[codes].tobytes(), np.arange(n + 1, dtype=np.int64) * L
+
+
+def synth_reads_packed_torch(seqs, n, read_len, seed, device, chunk=1 << 20, frac_random=0.10, err=0.01, n_rate=0.001,
+                             return_codes_of_first=0):
+    """Bench-scale twin of synth_reads + pack_codes on the GPU (torch Philox generator, seeded): returns the packed
+    int64 tensor [n, stride] in the device layout; optionally also the uint8 codes of the first `return_codes_of_first`
+    reads (for a parity spot check against the oracle). Same distribution as synth_reads, different PRNG stream."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    lens = torch.tensor([len(s) for s in seqs], dtype=torch.int64, device=device)
+    offs = torch.zeros(len(seqs) + 1, dtype=torch.int64, device=device)
+    offs[1:] = torch.cumsum(lens, 0)
+    flat = torch.from_numpy(np.concatenate(seqs).astype(np.uint8)).to(device)
+    nwb, nwn = (read_len + 31) // 32, (read_len + 63) // 64
+    out = torch.empty((n, nwb + nwn), dtype=torch.int64, device=device)
+    ar = torch.arange(read_len, dtype=torch.int64, device=device)
+    sh2 = (torch.arange(32, dtype=torch.int64, device=device) * 2)[None, None, :]
+    sh1 = torch.arange(64, dtype=torch.int64, device=device)[None, None, :]
+    first_codes = None
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        allele = torch.randint(0, len(seqs), (m,), generator=g, device=device)
+        start = (torch.rand(m, generator=g, device=device, dtype=torch.float64) * (lens[allele] - read_len + 1)).to(torch.int64)
+        reads = flat[(offs[allele] + start)[:, None] + ar[None, :]]
+        rev = torch.rand(m, generator=g, device=device) < 0.5
+        reads = torch.where(rev[:, None], (3 - reads).flip(1), reads)
+        sub = torch.rand((m, read_len), generator=g, device=device) < err
+        reads = torch.where(sub, (reads + torch.randint(1, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8)) & 3, reads)
+        rnd = torch.rand(m, generator=g, device=device) < frac_random
+        reads = torch.where(rnd[:, None], torch.randint(0, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8), reads)
+        isn = torch.rand((m, read_len), generator=g, device=device) < n_rate
+        reads = torch.where(isn, torch.full_like(reads, 4), reads)
+        if lo == 0 and return_codes_of_first:
+            first_codes = reads[:return_codes_of_first].cpu().numpy()
+        two = torch.where(isn, torch.zeros_like(reads), reads).to(torch.int64)
+        pad = torch.zeros((m, nwb * 32), dtype=torch.int64, device=device)
+        pad[:, :read_len] = two
+        out[lo:lo + m, :nwb] = (pad.view(m, nwb, 32) << sh2).sum(dim=2)       # disjoint bit fields: sum == or
+        npad = torch.zeros((m, nwn * 64), dtype=torch.int64, device=device)
+        npad[:, :read_len] = isn.to(torch.int64)
+        out[lo:lo + m, nwb:] = (npad.view(m, nwn, 64) << sh1).sum(dim=2)
+    return (out, first_codes) if return_codes_of_first else out
