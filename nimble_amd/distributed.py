@@ -9,17 +9,31 @@ threads do when they merge their per-thread {feature set -> count} maps at the e
 import numpy as np
 
 
+def unique_rows(rows):
+    """(unique rows in lexicographic order (word 0 most significant), inverse index) of a [n, W] uint64 array.
+    np.lexsort over the W columns: ~100x faster than np.unique(axis=0) on wide rows."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    n, W = rows.shape
+    if n == 0:
+        return rows, np.zeros(0, dtype=np.int64)
+    order = np.lexsort(tuple(rows[:, w] for w in range(W - 1, -1, -1))) if W else np.arange(n)
+    srt = rows[order]
+    new = np.ones(n, dtype=bool)
+    if W:
+        new[1:] = (srt[1:] != srt[:-1]).any(axis=1)
+    else:
+        new[1:] = False
+    gid = np.cumsum(new) - 1
+    inverse = np.empty(n, dtype=np.int64)
+    inverse[order] = gid
+    return srt[new], inverse
+
+
 def merge_dictionaries(rows_list):
     """rows_list: list of [n_i, W] uint64 arrays. Returns the agreed dictionary: unique rows in lexicographic order."""
     W = rows_list[0].shape[1] if rows_list else 0
     allrows = np.concatenate([r.reshape(-1, W) for r in rows_list], axis=0) if rows_list else np.zeros((0, W), np.uint64)
-    if allrows.shape[0] == 0:
-        return allrows
-    return np.unique(allrows, axis=0)
-
-
-def _row_keys(rows):
-    return [r.tobytes() for r in np.ascontiguousarray(rows)]
+    return unique_rows(allrows)[0]
 
 
 def reduce_class_counts(rows, counts, device=None, group=None):
@@ -32,12 +46,8 @@ def reduce_class_counts(rows, counts, device=None, group=None):
     counts = np.ascontiguousarray(counts, dtype=np.int64)
     W = rows.shape[1]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        glob = merge_dictionaries([rows])
-        pos = {k: i for i, k in enumerate(_row_keys(glob))}
-        out = np.zeros(glob.shape[0], dtype=np.int64)
-        for k, c in zip(_row_keys(rows), counts):
-            out[pos[k]] += c
-        return glob, out
+        glob, inv = unique_rows(rows)
+        return glob, np.bincount(inv, weights=counts, minlength=glob.shape[0]).astype(np.int64)
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cpu")
     # 1. dictionary agreement: sizes, then padded rows
@@ -52,12 +62,12 @@ def reduce_class_counts(rows, counts, device=None, group=None):
     gathered = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(gathered, pad, group=group)
     parts = [g[:s, :W].cpu().numpy().view(np.uint64) for g, s in zip(gathered, sizes)]
-    glob = merge_dictionaries(parts)
-    # 2. ONE all-reduce of the dense per-class count vector
-    pos = {k: i for i, k in enumerate(_row_keys(glob))}
+    glob, inv = unique_rows(np.concatenate(parts, axis=0))
+    # 2. ONE all-reduce of the dense per-class count vector (this rank's rows are segment `rank` of the concatenation)
+    rank = dist.get_rank(group)
+    lo = sum(sizes[:rank])
     dense = np.zeros(max(glob.shape[0], 1), dtype=np.int64)
-    for k, c in zip(_row_keys(rows), counts):
-        dense[pos[k]] += c
+    np.add.at(dense, inv[lo:lo + sizes[rank]], counts)
     t = torch.from_numpy(dense).to(dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return glob, t.cpu().numpy()[:glob.shape[0]]
