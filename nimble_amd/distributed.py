@@ -39,15 +39,15 @@ def merge_dictionaries(rows_list):
 def reduce_class_counts(rows, counts, device=None, group=None):
     """rows [n, W] uint64 / counts [n] int64 of THIS rank -> (global_rows [G, W], global_counts [G]) on every rank.
 
-    With no initialised process group (single GPU) this is the identity up to the canonical row order."""
+    With no initialised process group (single GPU) this is the identity (device id order); with several ranks the
+    agreed dictionary is in lexicographic row order on every rank."""
     import torch
     import torch.distributed as dist
     rows = np.ascontiguousarray(rows, dtype=np.uint64)
     counts = np.ascontiguousarray(counts, dtype=np.int64)
     W = rows.shape[1]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        glob, inv = unique_rows(rows)
-        return glob, np.bincount(inv, weights=counts, minlength=glob.shape[0]).astype(np.int64)
+        return rows, counts  # one rank: the device class table already holds each set exactly once
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cpu")
     # 1. dictionary agreement: sizes, then padded rows

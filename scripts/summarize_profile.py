@@ -29,7 +29,7 @@ def main(out):
         cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]
         print(",".join(cols))
         for r in rows[:12]:
-            print(",".join(str(r.get(c, "")) for c in cols))
+            print(",".join(str(r.get(c, ""))[:110] for c in cols))
     for tag in ("pmc_fetch", "pmc_write", "pmc_l2"):
         for f in find(os.path.join(out, tag), "*counter_collection.csv"):
             print(f"\n## {tag} ({os.path.relpath(f, out)}) — per-dispatch counter values of the alignment kernel")
