@@ -127,12 +127,13 @@ int32_t nb_counts_device_ptr(nb_ctx* ctx, void** d_counts, int64_t* capacity);
 
 /* ---- FASTQ(.gz) ingest (host): replaces the Rust binary's decode of each "--input" file (__main__.py:177-179) and,
  * for 10x R1, the CB/UMI split of /root/reference/nimble/fastq_barcode_processor.py:131-141. Packs straight into the
- * device layout. cb_out/umi_out (fixed width cb_len/umi_len per record) and out_words/out_lens may each be NULL. ---- */
+ * device layout. cb_out/umi_out/cbqual_out (fixed width cb_len/umi_len/cb_len per record; cbqual = quality characters
+ * of the CB bases) and out_words/out_lens may each be NULL. ---- */
 typedef struct nb_fastq nb_fastq;
 int32_t nb_fastq_open(const char* path, nb_fastq** out);
 int32_t nb_fastq_close(nb_fastq* fq);
 int32_t nb_fastq_next_batch(nb_fastq* fq, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
-                            int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len);
+                            int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len, char* cbqual_out);
 
 /* name of the kernel nb_align_batch launches for this shape (for matching rocprofv3 kernel-trace rows) */
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired);

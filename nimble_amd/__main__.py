@@ -1,0 +1,76 @@
+"""Command line: `python -m nimble_amd {generate,align,report}` with the reference's flags.
+
+Flag surface copied from /root/reference/nimble/__main__.py:389-418 (generate :389-392, align :394-401, report
+:403-418). `download`, `plot` and `fastq-to-bam` exist in the reference but are outside the hot path (network fetch of
+the Rust binary, HTML plotting, pysam BAM writing): they are accepted and answered with an explanatory error."""
+import argparse
+import sys
+
+from .align import TenxOptions, align
+from .library import generate
+from .report import report
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="nimble align")
+    parser.add_argument("-v", "--version", action="version", version="nimble_amd 0.1 (MI355X engine, C-ABI 1)")
+    sub = parser.add_subparsers(title="subcommands", dest="subcommand")
+
+    g = sub.add_parser("generate")
+    g.add_argument("--file", help="The file to process.", type=str, required=True)
+    g.add_argument("--opt-file", help="The optional file to process.", type=str, default=None)
+    g.add_argument("--output_path", help="The path to the output file.", type=str, required=True)
+
+    a = sub.add_parser("align")
+    a.add_argument("--reference", help="The reference genome to align to.", type=str, required=True)
+    a.add_argument("--output", help="The path to the output file.", type=str, required=True)
+    a.add_argument("--input", help="The input reads.", type=str, required=True, nargs="+")
+    a.add_argument("-c", "--num_cores", help="The number of cores to use for alignment.", type=int, default=1)
+    a.add_argument("--strand_filter", help="Filter reads based on strand information.", type=str, default="unstranded")
+    a.add_argument("--trim", help="Configuration for trimming read-data, in the format <TARGET_LENGTH>:<STRICTNESS>, comma-separated, one entry for each passed library", type=str, default="")
+    a.add_argument("--tmpdir", help="Path to a temporary directory for sorting .bam files", type=str, default=None)
+    # extensions (neutral when absent): 10x R1 barcode reads straight from FASTQ, GPU choice
+    a.add_argument("--tenx", help="Treat --input R1 R2 as 10x reads: R1 = cell barcode + UMI, R2 = cDNA.", action="store_true", default=False)
+    a.add_argument("--map", help="Cell barcode whitelist file (one CB per line, .gz or plain text); enables Hamming-1 correction.", type=str, default=None)
+    a.add_argument("--cb-length", help="Length of cell barcode (default: 16).", type=int, default=16)
+    a.add_argument("--umi-length", help="Length of UMI (default: 12).", type=int, default=12)
+    a.add_argument("--device", help="GPU index (default 0).", type=int, default=0)
+
+    r = sub.add_parser("report")
+    r.add_argument("-i", "--input", help="The input file.", type=str, required=True)
+    r.add_argument("-o", "--output", help="The path to the output file.", type=str, required=True)
+    r.add_argument("-s", "--summarize", help="CSV list of columns to summarize.", type=str, default=None)
+    r.add_argument("-t", "--threshold", help="Proportional count threshold for filtering features (default: 0.05).", type=float, default=0.05)
+    r.add_argument("--disable_thresholding", help="Disable the per-UMI proportional count thresholding algorithm.", action="store_true", default=False)
+
+    for name in ("download", "plot", "fastq-to-bam"):
+        sub.add_parser(name, add_help=False)
+    return parser
+
+
+def main(argv=None):
+    parser = build_parser()
+    args, extra = parser.parse_known_args(argv)
+    if args.subcommand in ("download", "plot", "fastq-to-bam"):
+        print(f"Error -- `{args.subcommand}` is not part of this build: the aligner is the in-tree libnimble_amd.so (nothing to "
+              "download), plots are out of scope, and 10x FASTQ is consumed directly by `align --tenx`.", file=sys.stderr)
+        return 2
+    if extra:
+        parser.error("unrecognized arguments: " + " ".join(extra))
+    if args.subcommand == "generate":
+        generate(args.file, args.opt_file, args.output_path)
+        return 0
+    if args.subcommand == "align":
+        tenx = TenxOptions(args.map, args.cb_length, args.umi_length) if args.tenx else None
+        return align(args.reference, args.output, args.input, args.num_cores, args.strand_filter, args.trim, args.tmpdir,
+                     tenx=tenx, device_id=args.device)
+    if args.subcommand == "report":
+        cols = args.summarize.split(",") if args.summarize else None
+        report(args.input, args.output, cols, args.threshold, args.disable_thresholding)
+        return 0
+    parser.print_help()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

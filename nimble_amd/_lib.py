@@ -60,8 +60,8 @@ SIGNATURES = {
     "nb_kernel_name": (ct.c_char_p, [ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32]),
     "nb_fastq_open": (ct.c_int32, [ct.c_char_p, ct.POINTER(ct.c_void_p)]),
     "nb_fastq_close": (ct.c_int32, [ct.c_void_p]),
-    "nb_fastq_next_batch": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.c_int32, c_u64p, c_u16p, c_i64p, ct.c_char_p,
-                                         ct.c_int32, ct.c_char_p, ct.c_int32]),
+    "nb_fastq_next_batch": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.c_int32, ct.c_void_p, ct.c_void_p, c_i64p, ct.c_void_p,
+                                         ct.c_int32, ct.c_void_p, ct.c_int32, ct.c_void_p]),
 }
 
 

@@ -1,0 +1,248 @@
+"""`nimble align` host path: the drop-in for the subprocess call at /root/reference/nimble/__main__.py:195.
+
+align() keeps the reference's signature and return convention (__main__.py:153-211): it returns the exit code the CLI
+passes to sys.exit, 0 on success. Instead of building an argv and spawning the Rust binary, it loads each library JSON,
+builds the index, streams the FASTQ input in batches through the C-ABI (nb_fastq_next_batch -> nb_align_batch) and
+writes one TSV per library at append_path_string(output, "." + stem) when several libraries are given
+(__main__.py:182-189). Output shapes: docs/SPEC.md §5.
+
+Input modes
+  * one FASTQ(.gz): single-end bulk -> "nimble_features<TAB>nimble_score" per distinct feature list.
+  * two FASTQ(.gz) + tenx options: R1 carries CB+UMI (fastq_barcode_processor.py:131-141), R2 is aligned; one row per
+    called read with r1_CB / r1_UB — what the reference obtains via `fastq-to-bam` + BAM input.
+  * two FASTQ(.gz) without tenx options: a biological pair (needs the paired kernel).
+  * BAM: not available in this build (no htslib/pysam in the image) -> error, non-zero exit.
+"""
+import ctypes as ct
+import gzip
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import _lib, barcodes, engine
+from .library import Library
+from .utils import append_path_string, parse_trim
+
+BATCH_READS = 1 << 22
+MAX_READ_LEN = 339      # NB_MAX_POSITIONS + k - 1 at k = 20
+COV_COLUMNS = ["r1_forward_score", "r1_reverse_score", "r2_forward_score", "r2_reverse_score"]
+
+
+class TenxOptions:
+    """R1 = cell barcode + UMI carrier (defaults of the reference's fastq-to-bam: __main__.py:430-431)."""
+
+    def __init__(self, whitelist=None, cb_length=16, umi_length=12):
+        self.whitelist, self.cb_length, self.umi_length = whitelist, int(cb_length), int(umi_length)
+
+
+class FastqReader:
+    def __init__(self, path):
+        self._h = ct.c_void_p()
+        _lib.check(_lib.lib().nb_fastq_open(path.encode(), ct.byref(self._h)))
+
+    def next_batch(self, max_reads, max_len=None, barcodes_only=False, cb_len=0, umi_len=0):
+        """Returns dict(n, words, lens, cb, umi, cbq)."""
+        n = ct.c_int64()
+        out = {}
+        if barcodes_only:
+            cb = np.zeros((max_reads, cb_len), dtype="S1")
+            umi = np.zeros((max_reads, umi_len), dtype="S1")
+            cbq = np.zeros((max_reads, cb_len), dtype="S1")
+            _lib.check(_lib.lib().nb_fastq_next_batch(self._h, max_reads, 1, None, None, ct.byref(n), cb.ctypes.data, cb_len,
+                                                      umi.ctypes.data, umi_len, cbq.ctypes.data))
+            out.update(cb=cb[:n.value], umi=umi[:n.value], cbq=cbq[:n.value])
+        else:
+            stride = engine.packed_stride_words(max_len)
+            words = np.zeros((max_reads, stride), dtype=np.uint64)
+            lens = np.zeros(max_reads, dtype=np.uint16)
+            _lib.check(_lib.lib().nb_fastq_next_batch(self._h, max_reads, max_len, words.ctypes.data, lens.ctypes.data, ct.byref(n),
+                                                      None, 0, None, 0, None))
+            out.update(words=words[:n.value], lens=lens[:n.value])
+        out["n"] = n.value
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().nb_fastq_close(self._h)
+            self._h = None
+
+
+class LibraryRun:
+    """One reference library on one GPU: index, context, class -> feature-string cache, output writer."""
+
+    def __init__(self, lib_path, out_path, strand_filter, device_id, per_read):
+        self.lib = Library(lib_path)
+        c = self.lib.config
+        self.cfg = engine.make_config(k=self.lib.k, score_threshold=c["score_threshold"], score_filter=c["score_filter"],
+                                      score_percent=c["score_percent"], num_mismatches=c["num_mismatches"],
+                                      discard_multiple_matches=c["discard_multiple_matches"], intersect_level=c["intersect_level"],
+                                      require_valid_pair=c["require_valid_pair"], strand_filter=strand_filter)
+        self.max_hits = int(c["max_hits_to_report"])
+        self.multi_hits = int(c["discard_multi_hits"])
+        self.index = engine.Index(self.lib.sequences, self.lib.k)
+        self.ctx = engine.Context(device_id, max_classes=1 << 20)
+        self.ctx.upload(self.index)
+        self.out_path = out_path
+        self.per_read = per_read
+        self.class_feature = []     # class id -> feature string, or None when a class-level filter rejects it
+        self.class_reason = []
+        self.bulk = {}
+        self.n_rows = 0
+        self.fh = None
+        if per_read:
+            self.fh = gzip.open(out_path, "wt") if out_path.endswith(".gz") else open(out_path, "w")
+            self.fh.write("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n")
+
+    def refresh_classes(self):
+        """Map newly interned classes to feature strings; apply the feature-level filters of docs/SPEC.md §4."""
+        rows, counts = self.ctx.classes()
+        for cid in range(len(self.class_feature), rows.shape[0]):
+            feats = self.lib.feature_list(engine.bits_to_members(rows[cid]))
+            reason = 0
+            if len(feats) > self.max_hits:
+                reason = 10   # NB_MAX_HITS
+            elif self.multi_hits > 0 and len(feats) > self.multi_hits:
+                reason = 11   # NB_MULTI_HITS
+            self.class_feature.append(",".join(feats) if reason == 0 else None)
+            self.class_reason.append(reason)
+        return rows, counts
+
+    def finish(self):
+        if self.per_read:
+            self.fh.close()
+            return
+        _, counts = self.refresh_classes()
+        for cid, cnt in enumerate(counts):
+            f = self.class_feature[cid]
+            if f is not None and cnt:
+                self.bulk[f] = self.bulk.get(f, 0) + int(cnt)
+        opener = gzip.open if self.out_path.endswith(".gz") else open
+        with opener(self.out_path, "wt") as fh:
+            fh.write("nimble_features\tnimble_score\n")
+            for f in sorted(self.bulk):
+                fh.write(f"{f}\t{self.bulk[f]}\n")
+        self.n_rows = len(self.bulk)
+
+
+def _write_per_read(run, cls, info, cov, cbs, umis):
+    run.refresh_classes()
+    feat = run.class_feature
+    called = np.nonzero((info["reason"] == 0) & (cls != engine.NO_CLASS))[0]
+    w = run.fh.write
+    for i in called:
+        f = feat[cls[i]]
+        if f is None or cbs[i] is None:
+            continue
+        w(f"{f}\t{info['mates'][i]}\t{cbs[i]}\t{umis[i]}\t{cov[i, 0]}\t{cov[i, 1]}\t{cov[i, 2]}\t{cov[i, 3]}\n")
+        run.n_rows += 1
+
+
+def align(reference, output, input, num_cores=1, strand_filter="unstranded", trim="", tmpdir=None, tenx=None, device_id=0,
+          batch_reads=BATCH_READS):
+    """Same positional arguments and return value as the reference's align() (__main__.py:153). `tenx`, `device_id`
+    and `batch_reads` are extensions with neutral defaults."""
+    try:
+        import torch
+        print("Aligning input data to the reference libraries")
+        sys.stdout.flush()
+        if os.path.splitext(input[0])[-1].lower() == ".bam":
+            raise NotImplementedError("BAM input needs htslib/pysam, which this image lacks; pass FASTQ (use the tenx options "
+                                      "for R1 barcode reads instead of `fastq-to-bam`)")
+        if len(input) > 2:
+            raise ValueError("--input takes one or two FASTQ files")
+        if strand_filter not in engine.STRAND_FILTERS:
+            raise ValueError(f"--strand_filter must be one of {sorted(engine.STRAND_FILTERS)}")
+        libs = reference.split(",")
+        parse_trim(trim, len(libs))
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X/HIP device visible: nimble_amd has no CPU alignment path")
+        dev = torch.device("cuda", device_id)
+        per_read = tenx is not None
+        if per_read and len(input) != 2:
+            raise ValueError("tenx mode needs --input R1.fastq R2.fastq")
+        paired = len(input) == 2 and not per_read
+        runs = []
+        for lib in libs:
+            suffix = "." + os.path.splitext(os.path.basename(lib))[0] if len(libs) > 1 else ""
+            runs.append(LibraryRun(lib, append_path_string(output, suffix), strand_filter, device_id, per_read))
+        corrector = None
+        if per_read and tenx.whitelist:
+            corrector = barcodes.BarcodeCorrector(barcodes.load_whitelist(tenx.whitelist))
+        r1 = FastqReader(input[0])
+        r2 = FastqReader(input[1]) if len(input) == 2 else None
+        total, t0 = 0, time.time()
+        while True:
+            if per_read:
+                b1 = r1.next_batch(batch_reads, barcodes_only=True, cb_len=tenx.cb_length, umi_len=tenx.umi_length)
+                b2 = r2.next_batch(batch_reads, MAX_READ_LEN)
+                if b1["n"] != b2["n"]:
+                    raise ValueError("R1 and R2 FASTQ files have different numbers of records")
+                seq, mate = b2, None
+            else:
+                seq = r1.next_batch(batch_reads, MAX_READ_LEN)
+                mate = r2.next_batch(batch_reads, MAX_READ_LEN) if paired else None
+                if paired and mate["n"] != seq["n"]:
+                    raise ValueError("R1 and R2 FASTQ files have different numbers of records")
+            n = seq["n"]
+            if n == 0:
+                break
+            max_len = max(int(seq["lens"].max()), 1)
+            stride = engine.packed_stride_words(max_len)
+            full = engine.packed_stride_words(MAX_READ_LEN)
+            words = _repack(seq["words"], MAX_READ_LEN, max_len) if stride != full else seq["words"]
+            d_reads = torch.from_numpy(words.view(np.int64)).to(dev)
+            d_lens = torch.from_numpy(seq["lens"].view(np.int16)).to(dev)
+            d_mates = d_mlens = None
+            mmax = 0
+            if mate is not None:
+                mmax = max(int(mate["lens"].max()), 1)
+                mw = _repack(mate["words"], MAX_READ_LEN, mmax) if engine.packed_stride_words(mmax) != full else mate["words"]
+                d_mates = torch.from_numpy(mw.view(np.int64)).to(dev)
+                d_mlens = torch.from_numpy(mate["lens"].view(np.int16)).to(dev)
+            out_class = torch.empty(n, dtype=torch.int32, device=dev)
+            out_info = torch.empty(n, dtype=torch.int32, device=dev)
+            out_cov = torch.empty(n, dtype=torch.int64, device=dev) if per_read else None
+            cbs = umis = None
+            if per_read:
+                raw_cb = [x.tobytes().decode() for x in b1["cb"]]
+                umis = [x.tobytes().decode() for x in b1["umi"]]
+                if corrector:
+                    cbq = [x.tobytes().decode() for x in b1["cbq"]]
+                    cbs = [corrector.correct(c, q) for c, q in zip(raw_cb, cbq)]
+                else:
+                    cbs = raw_cb
+            for run in runs:
+                run.ctx.align_batch(run.cfg, d_reads, d_lens, max_len, out_class, out_info, out_cov, mates=d_mates, mate_lens=d_mlens,
+                                    mate_max_len=mmax, n=n)
+                run.ctx.sync()
+                if per_read:
+                    _write_per_read(run, out_class.cpu().numpy().view(np.uint32), engine.decode_info(out_info.cpu().numpy().view(np.uint32)),
+                                    engine.decode_cov(out_cov.cpu().numpy().view(np.uint64)), cbs, umis)
+            total += n
+        for run in runs:
+            run.finish()
+            reasons = run.ctx.reasons()
+            print(f"{run.lib.stem}: {total} templates, {int(reasons[0])} called, {run.n_rows} output rows -> {run.out_path}")
+            print("  reasons: " + ", ".join(f"{engine.REASONS[i]}={int(v)}" for i, v in enumerate(reasons) if v))
+        if corrector:
+            print(f"cell barcodes: {corrector.stats}")
+        print(f"Aligned {total} templates in {time.time() - t0:.2f} s")
+        r1.close()
+        if r2:
+            r2.close()
+        print("Retaining all input files.")
+        return 0
+    except Exception as e:  # exit-code convention of the process boundary (__main__.py:198,211)
+        print(f"Error -- alignment failed: {type(e).__name__}: {e}", file=sys.stderr)
+        return 1
+
+
+def _repack(words, from_len, to_len):
+    """Re-stride packed reads from layout(max_len=from_len) to layout(max_len=to_len <= from_len)."""
+    nwb_f, nwb_t, nwn_t = (from_len + 31) // 32, (to_len + 31) // 32, (to_len + 63) // 64
+    out = np.empty((words.shape[0], nwb_t + nwn_t), dtype=np.uint64)
+    out[:, :nwb_t] = words[:, :nwb_t]
+    out[:, nwb_t:] = words[:, nwb_f:nwb_f + nwn_t]
+    return out

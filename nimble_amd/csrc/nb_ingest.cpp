@@ -69,9 +69,10 @@ int32_t nb_fastq_close(nb_fastq* q) { if (q) { if (q->f) gzclose(q->f); delete q
 // Reads up to max_reads records; *n_out = records read (0 = end of file).
 //   out_words != NULL: the whole sequence line is packed at stride nb_packed_stride_words(max_len), length to out_lens.
 //   cb_out / umi_out != NULL: bases [0, cb_len) and [cb_len, cb_len + umi_len) of the sequence line are copied, fixed
-//   width, to cb_out[i * cb_len] / umi_out[i * umi_len] (the 10x R1 layout).
+//   width, to cb_out[i * cb_len] / umi_out[i * umi_len] (the 10x R1 layout); cbqual_out != NULL additionally receives
+//   the quality characters of the CB bases (for the lowest-quality tie-break of the whitelist correction).
 int32_t nb_fastq_next_batch(nb_fastq* q, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
-                            int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len) {
+                            int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len, char* cbqual_out) {
   if (!q || !n_out || max_reads < 0) { nb::set_error("nb_fastq_next_batch: bad arguments"); return NB_ERR_INVALID; }
   const int nwb = (max_len + 31) / 32; const int64_t stride = nb_packed_stride_words(max_len);
   int64_t n = 0;
@@ -102,6 +103,10 @@ int32_t nb_fastq_next_batch(nb_fastq* q, int64_t max_reads, int32_t max_len, uin
     const char *b2, *e2;
     if (!next_line(q, &b2, &e2) || b2 == e2 || *b2 != '+') { nb::set_error("FASTQ parse error: missing '+' line in record " + std::to_string(q->record)); return NB_ERR_INVALID; }
     if (!next_line(q, &b2, &e2)) { nb::set_error("FASTQ parse error: missing quality line"); return NB_ERR_INVALID; }
+    if (cbqual_out) {
+      if (e2 - b2 < cb_len) { nb::set_error("FASTQ record " + std::to_string(q->record) + ": quality line shorter than cb_len"); return NB_ERR_INVALID; }
+      std::memcpy(cbqual_out + n * cb_len, b2, (size_t)cb_len);
+    }
     ++n; ++q->record;
   }
   *n_out = n; return NB_OK;

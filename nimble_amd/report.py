@@ -1,0 +1,182 @@
+"""`nimble report`: per-read TSV -> per-cell / per-feature UMI counts. pandas-free host code, bit-compatible.
+
+Mirrors /root/reference/nimble/__main__.py:213-302 (report, check_df_from_input, convert_df_to_proper_umi,
+write_empty_df) and /root/reference/nimble/utils.py:119-224 (per_umi_thresholding, umi_intersection, intersect_lists),
+including the float64 arithmetic the reference inherits from pandas: `groupby(...).sum()` on floats is
+Kahan-compensated in row order (verified in SURVEY.md §7), the running `total_score` is a plain left-to-right sum, the
+ratio test is `share / total < threshold` in IEEE double, and — a quirk kept on purpose — each thresholding round
+re-derives the shares from the ORIGINAL rows minus only that round's `to_drop` (utils.py:146-173), not the union of
+all rounds. Pinned by tests/golden/report_cases.json (outputs of the reference's own report()).
+
+Deviation (documented, tested): when every row ends up filtered the reference raises KeyError at __main__.py:283; this
+implementation writes the same empty output the reference writes for empty input (write_empty_df, __main__.py:299-302).
+"""
+import csv
+import os
+
+import numpy as np
+
+# strings pandas.read_csv treats as missing by default
+_NA = {"", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>", "N/A", "NA",
+       "NULL", "NaN", "None", "n/a", "nan", "null"}
+
+REQUIRED = ("nimble_features", "nimble_score", "r1_CB", "r1_UB")
+
+
+class _Kahan:
+    """pandas' group_sum accumulator (pandas/_libs/groupby.pyx): compensated sum in arrival order."""
+    __slots__ = ("s", "c")
+
+    def __init__(self):
+        self.s = np.float64(0.0)
+        self.c = np.float64(0.0)
+
+    def add(self, v):
+        y = v - self.c
+        t = self.s + y
+        c = (t - self.s) - y
+        self.c = c if c == c and abs(c) != np.inf else np.float64(0.0)
+        self.s = t
+
+
+def write_empty(output):
+    """write_empty_df (__main__.py:299-302): a zero-byte file."""
+    print("No data to parse from input file, writing empty output.")
+    open(output, "w").close()
+
+
+def _parse_score(tok):
+    try:
+        return int(tok)
+    except ValueError:
+        return float(tok)
+
+
+def read_rows(path):
+    """check_df_from_input + the column selection / null filtering of convert_df_to_proper_umi.
+    Returns None for "no data", else a list of (cb, umi, features_sorted, score)."""
+    if os.path.getsize(path) == 0:
+        return None
+    with open(path, newline="") as f:
+        lines = f.read().split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    lines = [ln[:-1] if ln.endswith("\r") else ln for ln in lines]
+    if not lines:
+        return None
+    header = lines[0].split("\t")
+    missing = [c for c in REQUIRED if c not in header]
+    body = [ln for ln in lines[1:] if ln != ""]   # pandas skips blank lines
+    if not body:
+        return None
+    if missing:
+        raise KeyError(f"input TSV lacks column(s) {missing}")
+    ix = [header.index(c) for c in REQUIRED]
+    rows, any_float = [], False
+    for ln in body:
+        fld = ln.split("\t")
+        vals = [fld[i] if i < len(fld) else "" for i in ix]
+        if any(v in _NA for v in vals):
+            continue  # dropna + != '' (__main__.py:244-245)
+        feats, score, cb, umi = vals
+        sc = _parse_score(score)
+        any_float |= isinstance(sc, float)
+        rows.append((cb, umi, ",".join(sorted(feats.split(","))), sc))
+    if any_float:
+        rows = [(cb, umi, ft, float(sc)) for cb, umi, ft, sc in rows]
+    return rows
+
+
+def merge_rows(rows):
+    """groupby(['cb','umi','features'])['nimble_score'].sum() (__main__.py:251): keys sorted, sums in file order."""
+    acc, is_float = {}, bool(rows) and isinstance(rows[0][3], float)
+    for cb, umi, ft, sc in rows:
+        key = (cb, umi, ft)
+        if is_float:
+            acc.setdefault(key, _Kahan()).add(np.float64(sc))
+        else:
+            acc[key] = acc.get(key, 0) + sc
+    out = []
+    for key in sorted(acc):
+        v = acc[key]
+        out.append((key[0], key[1], key[2], float(v.s) if is_float else v))
+    return out
+
+
+def _shares(group, drop):
+    """One pass of utils.py:125-133 / :158-173 over the UMI group's rows, skipping features in `drop`."""
+    sums, total, any_row = {}, 0, False
+    for _, _, ft, sc in group:
+        feats = [f for f in ft.split(",") if f not in drop]
+        if not feats:
+            continue
+        any_row = True
+        spf = np.float64(sc) / np.float64(len(feats))
+        total = total + sc
+        for f in feats:
+            sums.setdefault(f, _Kahan()).add(spf)
+    return sums, total, any_row
+
+
+def filter_umi_features(group, threshold):
+    """filter_umi_features (utils.py:120-191) for one (cb, umi) group: returns the surviving feature set."""
+    sums, total, _ = _shares(group, ())
+    while True:
+        if not sums:
+            return set()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tot = np.float64(total)
+            to_drop = {f for f, k in sums.items() if bool(k.s / tot < threshold)}
+        if not to_drop:
+            return set(sums)
+        sums, total, any_row = _shares(group, to_drop)
+        if not any_row:
+            return set()
+
+
+def report(input, output, summarize_columns_list=None, threshold=0.05, disable_thresholding=False):
+    """Same signature and output as the reference's report() (__main__.py:254)."""
+    rows = read_rows(input)
+    if rows is None:
+        write_empty(output)
+        return
+    rows = merge_rows(rows)
+    if not rows:
+        write_empty(output)
+        return
+    # group by (cb, umi); rows are already sorted by (cb, umi, features)
+    groups, cur = [], None
+    for r in rows:
+        if cur is None or (r[0], r[1]) != cur[0]:
+            cur = ((r[0], r[1]), [])
+            groups.append(cur)
+        cur[1].append(r)
+    per_umi = []   # ((cb, umi), intersected sorted feature list)
+    for key, grp in groups:
+        kept = []
+        if disable_thresholding:
+            kept = [set(ft.split(",")) for _, _, ft, _ in grp]
+        else:
+            survivors = filter_umi_features(grp, threshold)
+            for _, _, ft, _ in grp:
+                s = set(ft.split(",")) & survivors
+                if s:
+                    kept.append(s)     # rows whose filtered_features is '' are removed (utils.py:205)
+        if kept:
+            per_umi.append((key, sorted(set.intersection(*kept))))   # intersect_lists (utils.py:221-224)
+    if not per_umi:
+        write_empty(output)
+        return
+    empty = sum(1 for _, fl in per_umi if not fl)
+    print(f"Dropped {empty} UMIs due to empty intersections")
+    counts = {}
+    for (cb, _), fl in per_umi:
+        if fl:
+            k = (cb, ",".join(fl))
+            counts[k] = counts.get(k, 0) + 1
+    with open(output, "w", newline="") as f:
+        w = csv.writer(f, delimiter="\t", quoting=csv.QUOTE_MINIMAL, lineterminator="\n")
+        for cb, feat in sorted(counts):
+            w.writerow([feat, counts[(cb, feat)], cb])
+    if summarize_columns_list:
+        raise NotImplementedError("report -s/--summarize (reference __main__.py:307-310) is outside the hot-path scope of this build")

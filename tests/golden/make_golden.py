@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.json by RUNNING the reference's own Python (in the build container only).
+
+Usage (never on the GPU box — /root/reference does not exist there):
+    mkdir -p /tmp/stubs/Bio && touch /tmp/stubs/{distro,pysam,seaborn}.py /tmp/stubs/Bio/{__init__,SeqIO,Entrez}.py
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/tmp/stubs:/root/reference python /root/repo/tests/golden/make_golden.py
+
+The empty stub modules only satisfy imports the exercised functions never touch (`distro` is imported and unused at
+nimble/utils.py:3; pysam/seaborn/Bio are used only by sort_input_bam, plots and FASTA parsing). The fixtures are data:
+inputs and the outputs the reference produced for them (report(): nimble/__main__.py:254-302; generate() on CSV:
+__main__.py:45-65 + parse.py:78-139; append_path_string: utils.py:9-27). No reference source is copied.
+"""
+import json
+import os
+import random
+import sys
+import tempfile
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_report(m, text, threshold, disable):
+    with tempfile.TemporaryDirectory() as d:
+        i, o = os.path.join(d, "in.tsv"), os.path.join(d, "out.tsv")
+        with open(i, "w") as f:
+            f.write(text)
+        try:
+            m.report(i, o, None, threshold, disable)
+        except Exception as e:  # the reference itself raises on some inputs (e.g. every row filtered): record that
+            return {"raised": type(e).__name__}
+        return open(o).read() if os.path.exists(o) else None
+
+
+def tsv(rows, header=("nimble_features", "nimble_score", "r1_CB", "r1_UB"), extra=None):
+    cols = list(header) + (list(extra) if extra else [])
+    lines = ["\t".join(cols)]
+    for r in rows:
+        lines.append("\t".join(str(x) for x in r))
+    return "\n".join(lines) + "\n"
+
+
+def handmade():
+    c = []
+    c.append(("pinned_survey", tsv([("A,B", 10, "cell1", "UMI1"), ("C,A", 20, "cell1", "UMI1"), ("B,D", 15, "cell1", "UMI2"), ("G", 50, "cell3", "UMI3")])))
+    c.append(("basic_dominant", tsv([("A", 90, "c1", "u1"), ("B", 5, "c1", "u1"), ("A,B", 5, "c1", "u1")])))
+    c.append(("all_minor", tsv([(f"F{i}", 1, "c1", "u1") for i in range(30)])))
+    c.append(("tie_at_threshold", tsv([("A", 95, "c1", "u1"), ("B", 5, "c1", "u1")])))
+    c.append(("zero_scores", tsv([("A", 0, "c1", "u1"), ("B", 0, "c1", "u1"), ("A,B", 0, "c1", "u2")])))
+    c.append(("dup_feature_in_row", tsv([("A,A,B", 30, "c1", "u1"), ("B", 1, "c1", "u1")])))
+    c.append(("huge_scores", tsv([("A", 10 ** 12, "c1", "u1"), ("B", 10 ** 10, "c1", "u1"), ("A,B", 3 * 10 ** 11, "c1", "u1")])))
+    c.append(("float_scores", tsv([("A", 0.7, "c1", "u1"), ("B", 0.1, "c1", "u1"), ("A,B", 0.2, "c1", "u1"), ("C", 0.04, "c1", "u1")])))
+    c.append(("unsorted_features_merge", tsv([("B,A", 3, "c1", "u1"), ("A,B", 4, "c1", "u1"), ("C,B,A", 2, "c1", "u1")])))
+    c.append(("disjoint_sets_same_umi", tsv([("A", 10, "c1", "u1"), ("B", 10, "c1", "u1")])))
+    c.append(("multi_cell", tsv([("A", 5, "c2", "u1"), ("A", 5, "c1", "u1"), ("A,B", 5, "c1", "u2"), ("B", 9, "c1", "u3"), ("B,A", 1, "c2", "u9")])))
+    c.append(("cascade_drop", tsv([("A", 100, "c1", "u1"), ("B,C", 12, "c1", "u1"), ("C", 5, "c1", "u1"), ("D,B", 4, "c1", "u1")])))
+    c.append(("empty_fields", "nimble_features\tnimble_score\tr1_CB\tr1_UB\nA\t5\tc1\tu1\n\t5\tc1\tu1\nB\t5\t\tu1\nB\t5\tc1\t\nC\t\tc1\tu2\nC\t7\tc1\tu2\n"))
+    c.append(("extra_columns", tsv([("A", 5, "c1", "u1", 11, "x"), ("A,B", 6, "c1", "u1", 12, "y")], extra=("r1_POS", "r1_GN"))))
+    c.append(("header_only", "nimble_features\tnimble_score\tr1_CB\tr1_UB\n"))
+    c.append(("zero_bytes", ""))
+    c.append(("all_rows_null", "nimble_features\tnimble_score\tr1_CB\tr1_UB\n\t5\tc1\tu1\n"))
+    return c
+
+
+def random_tables(n_cases, seed):
+    rnd = random.Random(seed)
+    feats = [f"HLA-{x}*{i:02d}" for x in "ABC" for i in range(1, 5)] + ["KIR2DL1", "KIR3DL2", "MICA"]
+    cases = []
+    for k in range(n_cases):
+        rows = []
+        ncb, numi = rnd.randint(1, 4), rnd.randint(1, 6)
+        for _ in range(rnd.randint(1, 40)):
+            fs = rnd.sample(feats, rnd.randint(1, 4))
+            if rnd.random() < 0.1:
+                fs.append(fs[0])  # duplicate inside a row
+            rnd.shuffle(fs)
+            score = rnd.choice([1, 1, 1, 2, 2, 3, 5, 8, 20, 91]) if k % 5 else round(rnd.random() * 10, 3)
+            rows.append((",".join(fs), score, f"CB{rnd.randrange(ncb)}", f"UMI{rnd.randrange(numi)}"))
+        cases.append((f"random_{seed}_{k}", tsv(rows)))
+    return cases
+
+
+def main():
+    import nimble.__main__ as m
+    import nimble.utils as u
+
+    # ---- G2/G4: report() ----
+    out = []
+    for name, text in handmade() + random_tables(60, 1) + random_tables(60, 2):
+        for thr, dis in ((0.05, False), (0.0, False), (0.2, False), (0.5, False), (0.05, True)):
+            if name.startswith("random") and (thr, dis) not in ((0.05, False), (0.2, False), (0.05, True)) and hash(name) % 3:
+                continue
+            out.append({"name": name, "threshold": thr, "disable_thresholding": dis, "input": text,
+                        "output": run_report(m, text, thr, dis)})
+    json.dump(out, open(os.path.join(OUT, "report_cases.json"), "w"), indent=0)
+    print(f"report cases: {len(out)}")
+
+    # ---- G3: append_path_string ----
+    paths = ["/a/b/out.tsv.gz", "out.tsv", "out", "/x/y.z/out.tar.gz", "rel/dir/name.with.many.dots.txt", "/a/.hidden", "a/b.c/d", "", "/a/b/"]
+    g3 = [{"path": p, "suffix": s, "expected": u.append_path_string(p, s)} for p in paths for s in (".hla", "", ".lib-1")]
+    json.dump(g3, open(os.path.join(OUT, "append_path_string.json"), "w"), indent=0)
+
+    # ---- G1: generate() on a CSV library (exact JSON text) ----
+    g1 = []
+    csvs = {
+        "basic": "name,sequence,lineage\nA*01,ACGTACGTACGTACGTACGTAAAA,A\nA*02,ACGTACGTACGTACGTACGTCCCC,A\nB*01,TTTTACGTACGGGGTACGTACGTA,B\n",
+        "name_last": "sequence,locus,name\nACGTTTGACCA,x,s1\nGGGTTTGACCA,\"y,z\",s2\n",
+    }
+    for key, text in csvs.items():
+        with tempfile.TemporaryDirectory() as d:
+            p, o = os.path.join(d, f"my_{key}_lib.csv"), os.path.join(d, "lib.json")
+            open(p, "w").write(text)
+            m.generate(p, None, o)
+            g1.append({"name": key, "csv_name": f"my_{key}_lib.csv", "csv": text, "json": open(o).read()})
+    json.dump(g1, open(os.path.join(OUT, "generate_csv.json"), "w"), indent=0)
+    print("ok")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

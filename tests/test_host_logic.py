@@ -1,0 +1,135 @@
+"""Host-side pieces that need no GPU: path helper, library JSON, packing, FASTQ ingest, barcodes, CLI surface."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nimble_amd import barcodes, engine, library, synth, utils
+from nimble_amd.__main__ import build_parser
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_append_path_string_golden():
+    for c in json.load(open(os.path.join(HERE, "golden", "append_path_string.json"))):
+        assert utils.append_path_string(c["path"], c["suffix"]) == c["expected"], c
+
+
+def test_generate_csv_matches_reference_text(tmp_path):
+    for c in json.load(open(os.path.join(HERE, "golden", "generate_csv.json"))):
+        p, o = tmp_path / c["csv_name"], tmp_path / "lib.json"
+        p.write_text(c["csv"])
+        library.generate(str(p), None, str(o))
+        assert o.read_text() == c["json"], c["name"]
+
+
+def test_generate_fasta_and_collate(tmp_path):
+    fa = tmp_path / "my_hla_lib.fasta"
+    fa.write_text(">A*01 some description\nACGTAC\nGTAC\n>B*02\nTTTTGGGG\n")
+    o = tmp_path / "lib.json"
+    library.generate(str(fa), None, str(o))
+    cfg, data = json.load(open(o))
+    assert list(cfg)[:3] == ["score_threshold", "score_filter", "score_percent"] and cfg["data_type"] == "RNA"
+    assert data["headers"] == ["reference_genome", "sequence_name", "nt_length", "sequence"]
+    assert data["columns"] == [["my hla lib"] * 2, ["A*01", "B*02"], ["10", "8"], ["ACGTACGTAC", "TTTTGGGG"]]
+    meta = tmp_path / "meta.csv"
+    meta.write_text("name,lineage\nB*02,B\nA*01,A\n")
+    library.generate(str(fa), str(meta), str(o))
+    cfg, data = json.load(open(o))
+    assert data["headers"][-1] == "lineage" and data["columns"][1] == ["B*02", "A*01"]
+    assert data["columns"][3] == ["TTTTGGGG", "ACGTACGTAC"] and data["columns"][2] == ["8", "10"]
+    lib = library.Library(str(o))
+    assert lib.features == ["B*02", "A*01"] and lib.config["max_hits_to_report"] == 10
+    doc = json.load(open(o)); doc[0]["group_on"] = "lineage"; json.dump(doc, open(o, "w"))
+    lib = library.Library(str(o))
+    assert lib.features == ["B", "A"] and lib.feature_list([1, 0, 1]) == ["A", "B"]
+    doc[0]["group_on"] = "nope"; json.dump(doc, open(o, "w"))
+    with pytest.raises(ValueError):
+        library.Library(str(o))
+
+
+def test_pack_reads_matches_numpy_twin(built):
+    codes = synth.synth_reads([np.random.default_rng(0).integers(0, 4, 400, dtype=np.uint8)], 300, 150, seed=9, n_rate=0.02)
+    reads = [synth.codes_to_str(c) for c in codes]
+    words, lens = engine.pack_reads(reads, 150)
+    assert (lens == 150).all() and (words == synth.pack_codes(codes)).all()
+    w2, l2 = engine.pack_reads(["ACGTN", "", "acgt"], 70)
+    assert list(l2) == [5, 0, 4] and w2.shape == (3, 3 + 2)
+    assert w2[0, 0] == (0 | 1 << 2 | 2 << 4 | 3 << 6) and w2[0, 3] == 1 << 4 and w2[2, 0] == w2[0, 0] & 0xFF
+    with pytest.raises(engine._lib.NimbleError):
+        engine.pack_reads(["ACGT" * 10], 20)
+
+
+def test_fastq_ingest_plain_and_gzip(built, tmp_path):
+    from nimble_amd.align import FastqReader
+    recs = [("r1", "ACGTNACGT", "IIIIIIIII"), ("r2", "TTTT", "!!!!"), ("r3", "", "")]
+    text = "".join(f"@{n}\n{s}\n+\n{q}\n" for n, s, q in recs)
+    p, pz = tmp_path / "a.fastq", tmp_path / "a.fastq.gz"
+    p.write_text(text)
+    with gzip.open(pz, "wt") as f:
+        f.write(text)
+    want_w, want_l = engine.pack_reads([s for _, s, _ in recs], 20)
+    for path in (p, pz):
+        r = FastqReader(str(path))
+        b = r.next_batch(2, 20)
+        assert b["n"] == 2 and (b["words"] == want_w[:2]).all() and list(b["lens"]) == [9, 4]
+        b = r.next_batch(10, 20)
+        assert b["n"] == 1 and b["lens"][0] == 0
+        assert r.next_batch(10, 20)["n"] == 0
+        r.close()
+    r = FastqReader(str(p))
+    b = r.next_batch(1, barcodes_only=True, cb_len=4, umi_len=3)
+    assert b["cb"][0].tobytes() == b"ACGT" and b["umi"][0].tobytes() == b"NAC" and b["cbq"][0].tobytes() == b"IIII"
+    r.close()
+    bad = tmp_path / "bad.fastq"
+    bad.write_text("@x\nACGT\nIIII\n")
+    r = FastqReader(str(bad))
+    with pytest.raises(engine._lib.NimbleError):
+        r.next_batch(5, 20)
+
+
+def test_barcode_correction_rule():
+    wl = {"AAAA", "AAAC", "CAAT", "GGGG"}
+    c = barcodes.BarcodeCorrector(wl)
+    assert c.correct("AAAA", "IIII") == "AAAA"                       # exact
+    assert c.correct("GGGT", "IIII") == "GGGG"                       # single candidate
+    assert c.correct("TTTT", "IIII") is None                         # none -> dropped
+    # AAAT: candidates AAAA/AAAC (position 3) and CAAT (position 0); lowest quality at the differing base wins
+    assert barcodes.BarcodeCorrector(wl).correct("AAAT", "!III") == "CAAT"
+    assert barcodes.BarcodeCorrector(wl).correct("AAAT", "III!") == "AAAA"   # tie between AAAA/AAAC -> smallest
+    c2 = barcodes.BarcodeCorrector(wl)
+    assert c2.correct("AAAT", "!III") == "CAAT" and c2.correct("AAAT", "III!") == "CAAT"   # first sighting is cached
+    assert c2.stats == {"cb_perfect_match": 0, "cb_corrected": 2, "cb_no_correction": 0}
+
+
+def test_cli_flag_surface():
+    """Flags of the reference's align/report/generate parsers (__main__.py:389-418), same names, types and defaults."""
+    p = build_parser()
+    a = p.parse_args(["align", "--reference", "a.json,b.json", "--output", "o.tsv", "--input", "r1.fq", "r2.fq"])
+    assert (a.num_cores, a.strand_filter, a.trim, a.tmpdir) == (1, "unstranded", "", None) and a.input == ["r1.fq", "r2.fq"]
+    a = p.parse_args(["align", "--reference", "a", "--output", "o", "--input", "x", "-c", "8", "--strand_filter", "fiveprime", "--trim", "50:0.9"])
+    assert a.num_cores == 8 and a.strand_filter == "fiveprime"
+    r = p.parse_args(["report", "-i", "in", "-o", "out"])
+    assert r.threshold == 0.05 and r.disable_thresholding is False and r.summarize is None
+    r = p.parse_args(["report", "--input", "in", "--output", "out", "-t", "0.2", "--disable_thresholding", "-s", "a,b"])
+    assert r.threshold == 0.2 and r.disable_thresholding and r.summarize == "a,b"
+    g = p.parse_args(["generate", "--file", "x.fasta", "--opt-file", "m.csv", "--output_path", "lib.json"])
+    assert g.opt_file == "m.csv"
+    assert utils.parse_trim("50:0.9,40:0.5", 2) == [(50, 0.9), (40, 0.5)] and utils.parse_trim("", 3) is None
+    with pytest.raises(ValueError):
+        utils.parse_trim("50:0.9", 2)
+
+
+def test_align_without_gpu_returns_nonzero(built, tmp_path, capsys):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nimble_amd.align import align
+    fa = tmp_path / "l.fasta"; fa.write_text(">s\n" + "ACGT" * 20 + "\n")
+    library.generate(str(fa), None, str(tmp_path / "l.json"))
+    fq = tmp_path / "r.fastq"; fq.write_text("@r\n" + "ACGT" * 10 + "\n+\n" + "I" * 40 + "\n")
+    assert align(str(tmp_path / "l.json"), str(tmp_path / "o.tsv"), [str(fq)], 1, "unstranded", "", None) == 1
+    assert "no CPU alignment path" in capsys.readouterr().err
+    assert align(str(tmp_path / "l.json"), str(tmp_path / "o.tsv"), ["x.bam"], 1, "unstranded", "", None) == 1
