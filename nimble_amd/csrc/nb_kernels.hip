@@ -456,6 +456,234 @@ __global__ __launch_bounds__(256) void nb_align_se_kernel(DevIndex ix, DevClasse
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// general kernel: paired templates and/or num_mismatches > 0. Eager evaluation of every alignment of the template
+// (SPEC §4), one template per wave. Each sequence is first materialised in LDS in the orientation being mapped
+// (forward copy or reverse complement), so the mapper below only ever walks "forwards"; a tolerated mismatch
+// (SPEC §3: inside a unitig, budget M) is handled by PATCHING that LDS copy with the reference base and re-running the
+// data-parallel lookups — seeding always uses the unpatched hit mask, exactly as the sequential walk seeds from the
+// read itself.
+constexpr int GEN_NWB = (NB_MAX_POSITIONS + NB_MAX_K - 1 + 31) / 32;   // 11 words of bases
+constexpr int GEN_NWN = (NB_MAX_POSITIONS + NB_MAX_K - 1 + 63) / 64;   // 6 words of N mask
+constexpr int GEN_WORDS = GEN_NWB + GEN_NWN;
+
+// copy (rev = false) or reverse-complement (rev = true) a packed sequence of length L into LDS, same layout (nwb words
+// of bases, then N-mask words)
+__device__ __forceinline__ void stage_sequence(uint64_t* dst, const uint64_t* __restrict__ src, int nwb, int L, bool rev, int lane) {
+  const int nwn = (nwb + 1) >> 1;
+  for (int w = lane; w < nwb + nwn; w += 64) {
+    uint64_t v = 0;
+    if (!rev) v = src[w];
+    else if (w < nwb) {
+      for (int t = 0; t < 32; ++t) { const int jp = 32 * w + t; if (jp < L) { const int j = L - 1 - jp;
+          const bool isn = (src[nwb + (j >> 6)] >> (j & 63)) & 1;
+          const uint64_t c = isn ? 0ull : (3ull - ((src[j >> 5] >> ((j & 31) * 2)) & 3ull));
+          v |= c << (2 * t); } }
+    } else {
+      const int wn = w - nwb;
+      for (int t = 0; t < 64; ++t) { const int jp = 64 * wn + t; if (jp < L) { const int j = L - 1 - jp;
+          v |= ((src[nwb + (j >> 6)] >> (j & 63)) & 1ull) << t; } }
+    }
+    dst[w] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int NR> __device__ __forceinline__ bool test_bit(const Mask<NR>& m, int pos) {
+  uint64_t w = 0;
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) if (wi == (pos >> 6)) w = m.w[wi];
+  return (w >> (pos & 63)) & 1;
+}
+
+struct PatchReq { int base; int from_pos; int left; };   // base < 0: none
+
+// SPEC §3 on masks with tolerance decision points. Hseed: hits of the UNPATCHED sequence (seeding). R/LX: extendable
+// with the (patched) sequence; RI/LI: k-mer present and r_internal / l_internal.
+template <int NR>
+__device__ __forceinline__ int walk_general(const Mask<NR>& Hseed, const Mask<NR>& R, const Mask<NR>& LX, const Mask<NR>& RI,
+                                            const Mask<NR>& LI, int L, int K, bool can_patch, Mask<NR>& V, PatchReq& pr) {
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) V.w[wi] = 0;
+  pr.base = -1; pr.from_pos = 0; pr.left = 0;
+  const int last = L - K;
+  int p = ffs_stride3<NR>(Hseed, 0);
+  if (p < 0) return 0;
+  int cov = 0;
+  if (p >= L / 5 && p > 0) {
+    const int z = flz_upto<NR>(LX, p);          // lowest k-mer position reached going left
+    const int t = p - z;
+    if (t > 0) { cov += t; set_range<NR>(V, z, p - 1); }
+    if (z >= 1 && can_patch && test_bit<NR>(LI, z)) { pr.base = z - 1; pr.from_pos = z; pr.left = 1; return cov; }
+  }
+  for (;;) {
+    const int e = ffz_from<NR>(R, p);
+    cov += K + (e - p);
+    set_range<NR>(V, p, e);
+    const int b = e + K;
+    if (b < L && can_patch && test_bit<NR>(RI, e)) { pr.base = b; pr.from_pos = e; pr.left = 0; return cov; }
+    if (b > last) break;
+    p = ffs_stride3<NR>(Hseed, b);
+    if (p < 0) break;
+  }
+  return cov;
+}
+
+// Map the sequence staged in `seq` (LDS). Returns coverage; S.V / S.col describe the visited positions.
+template <int NR>
+__device__ __forceinline__ void map_staged(const DevIndex& ix, uint64_t* seq, int nwb, int L, int M, int lane, Strand<NR>& S) {
+  const int K = ix.K, P = L - K + 1;
+  Mask<NR> Hseed; int mm = 0;
+  for (int pass = 0;; ++pass) {
+    Mask<NR> H, R, LX, RI, LI; uint32_t pay[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int i = lane + 64 * r;
+      const PosFacts f = position_facts(ix, seq, nwb, L, i, i < P);
+      pay[r] = f.payF; S.col[r] = f.payF >> 10;
+      H.w[r] = __ballot(f.hF); R.w[r] = __ballot(f.rF); LX.w[r] = __ballot(f.lF);
+      RI.w[r] = __ballot(f.hF && ((f.payF >> 8) & 1u)); LI.w[r] = __ballot(f.hF && ((f.payF >> 9) & 1u));
+    }
+    if (pass == 0) Hseed = H;
+    PatchReq pr;
+    S.cov = any_set<NR>(Hseed) ? walk_general<NR>(Hseed, R, LX, RI, LI, L, K, mm < M, S.V, pr) : 0;
+    if (!any_set<NR>(Hseed)) { pr.base = -1;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) S.V.w[r] = 0; }
+    if (pr.base < 0) return;
+    // fetch the payload of k-mer position from_pos, patch the staged base with its unique extension
+    uint32_t pv = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) if (r == (pr.from_pos >> 6)) pv = pay[r];
+    const uint32_t src_pay = (uint32_t)__shfl((int)pv, pr.from_pos & 63, 64);
+    const uint32_t ext = pr.left ? ((src_pay >> 4) & 15u) : (src_pay & 15u);
+    const uint64_t u = (uint64_t)__builtin_ctz(ext | 16u);
+    if (lane == 0) {
+      const int q = pr.base;
+      seq[q >> 5] = (seq[q >> 5] & ~(3ull << ((q & 31) * 2))) | (u << ((q & 31) * 2));
+      seq[nwb + (q >> 6)] &= ~(1ull << (q & 63));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    ++mm;
+  }
+}
+
+// SPEC §4 checks 1-4 for one mapped strand; on success acc holds eq. Returns the reason (0 = valid).
+template <int NR, int TW>
+__device__ __forceinline__ int evaluate_alignment(const DevIndex& ix, const Strand<NR>& S, int L, const BatchArgs& a, int lane, uint64_t (&acc)[TW]) {
+  int rs = cheap_reason(S.cov, L, a);
+  if (rs) return rs;
+  const uint32_t n = intersect_visited<NR, TW>(ix, S, lane, acc);
+  if (n == 0) return NB_EMPTY_EQCLASS;
+  if (a.discard_multiple && n != 1) return NB_MULTIPLE_MATCH;
+  return 0;
+}
+
+template <int TW> struct OrientRes { bool valid; int reason, score, mates; uint64_t set[TW]; };
+
+// SPEC §4 "Per orientation": combine the two mates' alignments (r1: reason1/cov1/eq1, r2 likewise).
+template <int TW>
+__device__ __forceinline__ void combine_mates(bool paired, int reason1, int cov1, const uint64_t (&eq1)[TW], int reason2, int cov2,
+                                              const uint64_t (&eq2)[TW], const BatchArgs& a, OrientRes<TW>& o) {
+  o.valid = false; o.score = 0; o.mates = 0; o.reason = reason1;
+#pragma unroll
+  for (int t = 0; t < TW; ++t) o.set[t] = 0;
+  const bool v1 = reason1 == 0, v2 = paired && reason2 == 0;
+  if (!paired) {
+    if (v1) { o.valid = true; o.reason = 0; o.score = cov1; o.mates = 1;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) o.set[t] = eq1[t]; }
+    return;
+  }
+  if (v1 && v2) {
+    uint32_t ni = 0;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) ni += (uint32_t)__popcll(eq1[t] & eq2[t]);
+    ni = wave_sum_u32(ni);
+    const bool use_inter = (a.intersect_level == 2) || (a.intersect_level == 1 && ni != 0);
+    if (a.intersect_level == 2 && ni == 0) { o.reason = NB_EMPTY_EQCLASS; return; }
+#pragma unroll
+    for (int t = 0; t < TW; ++t) o.set[t] = use_inter ? (eq1[t] & eq2[t]) : (eq1[t] | eq2[t]);
+    o.valid = true; o.reason = 0; o.score = cov1 + cov2; o.mates = 2; return;
+  }
+  if (v1 || v2) {
+    if (a.require_valid_pair) { o.reason = NB_INVALID_PAIR; return; }
+    o.valid = true; o.reason = 0; o.score = v1 ? cov1 : cov2; o.mates = 1;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) o.set[t] = v1 ? eq1[t] : eq2[t];
+    return;
+  }
+  o.reason = reason1 > reason2 ? reason1 : reason2;
+}
+
+template <int NR, int TW>
+__global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevClasses ct, BatchArgs a) {
+  __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  __shared__ uint64_t s_seq[4][GEN_WORDS];
+  if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint64_t* seq = s_seq[wave];
+  const bool paired = a.mates != nullptr;
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave; r < a.n; r += nwaves) {
+    int L1 = a.lens ? (int)a.lens[r] : a.max_len; if (L1 > a.max_len) L1 = a.max_len;
+    int L2 = 0;
+    if (paired) { L2 = a.mate_lens ? (int)a.mate_lens[r] : a.mate_max_len; if (L2 > a.mate_max_len) L2 = a.mate_max_len; }
+    // four alignments: 0 = map(r1), 1 = map(rc(r1)), 2 = map(r2), 3 = map(rc(r2))
+    int rs[4], cov[4]; uint64_t eq[4][TW];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rs[j] = NB_TOO_SHORT; cov[j] = 0;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) eq[j][t] = 0;
+      const bool second = j >= 2;
+      if (second && !paired) continue;
+      const int L = second ? L2 : L1;
+      if (L < ix.K) continue;
+      const uint64_t* src = second ? a.mates + (size_t)r * a.mstride : a.reads + (size_t)r * a.stride;
+      const int nwb = second ? a.mnwb : a.nwb;
+      stage_sequence(seq, src, nwb, L, (j & 1) != 0, lane);
+      Strand<NR> S;
+      map_staged<NR>(ix, seq, nwb, L, a.num_mismatches, lane, S);
+      cov[j] = S.cov;
+      rs[j] = evaluate_alignment<NR, TW>(ix, S, L, a, lane, eq[j]);
+    }
+    OrientRes<TW> F, R;
+    combine_mates<TW>(paired, rs[0], cov[0], eq[0], rs[3], cov[3], eq[3], a, F);   // F = {map(r1), map(rc(r2))}
+    combine_mates<TW>(paired, rs[1], cov[1], eq[1], rs[2], cov[2], eq[2], a, R);   // R = {map(rc(r1)), map(r2)}
+    if (F.valid && a.strand_filter == NB_STRAND_THREEPRIME) { F.valid = false; F.reason = NB_STRAND; }
+    if (R.valid && a.strand_filter == NB_STRAND_FIVEPRIME) { R.valid = false; R.reason = NB_STRAND; }
+    int reason, score = 0, orient = 0, mates = 0; uint32_t cls = NB_NO_CLASS;
+    const bool pickR = R.valid && (!F.valid || R.score > F.score);
+    if (F.valid || R.valid) {
+      score = pickR ? R.score : F.score; orient = pickR ? 1 : 0; mates = pickR ? R.mates : F.mates;
+      if (score < a.score_filter) reason = NB_SCORE_FILTER;
+      else {
+        reason = NB_CALLED;
+        uint64_t acc[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = pickR ? R.set[t] : F.set[t];
+        cls = intern_class<TW>(ct, ix.W, lane, acc);
+        if (cls != NB_NO_CLASS && lane == 0) atomicAdd(&ct.counts[cls], 1ull);
+      }
+    } else reason = F.reason > R.reason ? F.reason : R.reason;
+    if (lane == 0) {
+      atomicAdd(&s_reason[reason], 1u);
+      if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
+      if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
+      if (a.out_cov) a.out_cov[r] = (uint64_t)(cov[0] & 0xFFFF) | ((uint64_t)(cov[1] & 0xFFFF) << 16) | ((uint64_t)(cov[2] & 0xFFFF) << 32) | ((uint64_t)(cov[3] & 0xFFFF) << 48);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host side of the C-ABI
 thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
@@ -507,6 +735,28 @@ static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStrea
   hipLaunchKernelGGL((nb_align_se_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
   NB_HIP(hipGetLastError());
   return NB_OK;
+}
+
+template <int NR, int TW>
+static int launch_general(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
+  long long blocks = (a.n + 3) / 4;
+  const long long cap = (long long)c->n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((nb_align_general_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
+  NB_HIP(hipGetLastError());
+  return NB_OK;
+}
+
+template <int TW>
+static int dispatch_general(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
+  switch (nr) {
+    case 1: return launch_general<1, TW>(c, ix, a, s);
+    case 2: return launch_general<2, TW>(c, ix, a, s);
+    case 3: return launch_general<3, TW>(c, ix, a, s);
+    case 4: return launch_general<4, TW>(c, ix, a, s);
+    default: return launch_general<5, TW>(c, ix, a, s);
+  }
 }
 
 template <int TW>
@@ -643,8 +893,9 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   if (!c->d_slots) { set_error("nb_align_batch: no index uploaded to this ctx"); return NB_ERR_INVALID; }
   if (cfg->k != c->K) { set_error("nb_align_batch: cfg.k differs from the uploaded index's k"); return NB_ERR_INVALID; }
   if (cfg->strand_filter < 0 || cfg->strand_filter > 3 || cfg->intersect_level < 0 || cfg->intersect_level > 2) { set_error("nb_align_batch: bad strand_filter/intersect_level"); return NB_ERR_INVALID; }
-  if (cfg->num_mismatches != 0) { set_error("nb_align_batch: num_mismatches > 0 is not implemented on the device yet"); return NB_ERR_UNSUPPORTED; }
-  if (d_mates) { set_error("nb_align_batch: paired templates are not implemented on the device yet"); return NB_ERR_UNSUPPORTED; }
+  if (cfg->num_mismatches < 0 || cfg->num_mismatches > 64) { set_error("nb_align_batch: num_mismatches must be in 0..64"); return NB_ERR_INVALID; }
+  if (d_mates && mate_max_len < 1) { set_error("nb_align_batch: mates given but mate_max_len < 1"); return NB_ERR_INVALID; }
+  if (!d_mates) mate_max_len = 0;
   const int lmax = max_len > mate_max_len ? max_len : mate_max_len;
   const int positions = lmax - c->K + 1;
   if (positions > NB_MAX_POSITIONS) { set_error("nb_align_batch: read longer than NB_MAX_POSITIONS + k - 1"); return NB_ERR_UNSUPPORTED; }
@@ -663,6 +914,8 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   a.discard_multiple = cfg->discard_multiple_matches; a.intersect_level = cfg->intersect_level;
   a.require_valid_pair = cfg->require_valid_pair; a.strand_filter = cfg->strand_filter;
   const int nr = positions < 1 ? 1 : (positions + 63) / 64;
+  if (d_mates || cfg->num_mismatches > 0)   // pairs and tolerated mismatches take the general (eager, LDS-staged) kernel
+    return (c->W <= 64) ? dispatch_general<1>(c, nr, ix, a, s) : dispatch_general<4>(c, nr, ix, a, s);
   return (c->W <= 64) ? dispatch_se<1>(c, nr, ix, a, s) : dispatch_se<4>(c, nr, ix, a, s);
 }
 
@@ -710,7 +963,7 @@ int32_t nb_counts_device_ptr(nb_ctx* c, void** d_counts, int64_t* capacity) {
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired) {
   static thread_local char buf[96];
   const int positions = max_len - k + 1; const int nr = positions < 1 ? 1 : (positions + 63) / 64; const int W = (n_seqs + 63) / 64;
-  std::snprintf(buf, sizeof buf, "nb_align_%s_kernel<%d, %d>", paired ? "pe" : "se", nr > 5 ? 5 : nr, W <= 64 ? 1 : 4);
+  std::snprintf(buf, sizeof buf, "nb_align_%s_kernel<%d, %d>", paired ? "general" : "se", nr > 5 ? 5 : nr, W <= 64 ? 1 : 4);
   return buf;
 }
 

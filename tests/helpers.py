@@ -4,7 +4,7 @@ import numpy as np
 from nimble_amd import engine, synth
 
 
-def run_gpu(index, cfg, words, lens, max_len, max_classes=1 << 16, device=0):
+def run_gpu(index, cfg, words, lens, max_len, max_classes=1 << 16, device=0, mate_words=None, mate_lens=None, mate_max_len=0):
     import torch
     ctx = engine.Context(device, max_classes=max_classes)
     ctx.upload(index)
@@ -15,7 +15,10 @@ def run_gpu(index, cfg, words, lens, max_len, max_classes=1 << 16, device=0):
     out_class = torch.empty(n, dtype=torch.int32, device=dev)
     out_info = torch.empty(n, dtype=torch.int32, device=dev)
     out_cov = torch.empty(n, dtype=torch.int64, device=dev)
-    ctx.align_batch(cfg, d_reads, d_lens, max_len, out_class, out_info, out_cov, n=n)
+    d_mates = torch.from_numpy(mate_words.view(np.int64)).to(dev) if mate_words is not None else None
+    d_mlens = torch.from_numpy(mate_lens.view(np.int16)).to(dev) if mate_lens is not None else None
+    ctx.align_batch(cfg, d_reads, d_lens, max_len, out_class, out_info, out_cov, mates=d_mates, mate_lens=d_mlens,
+                    mate_max_len=mate_max_len, n=n)
     ctx.sync()
     rows, counts = ctx.classes()
     res = {"class": out_class.cpu().numpy().view(np.uint32), "rows": rows, "counts": counts, "reasons": ctx.reasons()}

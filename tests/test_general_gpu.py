@@ -1,0 +1,99 @@
+"""GPU parity of the general kernel (paired templates, tolerated mismatches) against the oracle. Bit-exact."""
+import numpy as np
+import pytest
+
+from nimble_amd import engine, synth
+from tests.helpers import assert_same, library_strings, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_pairs(seqs, n, l1, l2, seed, frag=300, err=0.01):
+    """Fragment of length `frag` from a random allele/strand; r1 = first l1 bases, r2 = reverse complement of the last l2."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    r1 = np.zeros((n, l1), dtype=np.uint8); r2 = np.zeros((n, l2), dtype=np.uint8)
+    for i in range(n):
+        s = seqs[rng.integers(0, len(seqs))]
+        o = rng.integers(0, len(s) - frag + 1)
+        f = s[o:o + frag].copy()
+        if rng.random() < 0.5:
+            f = (3 - f)[::-1]
+        a, b = f[:l1].copy(), (3 - f[frag - l2:])[::-1].copy()
+        kind = rng.random()
+        if kind < 0.08:
+            a = rng.integers(0, 4, l1, dtype=np.uint8)            # r1 junk
+        elif kind < 0.16:
+            b = rng.integers(0, 4, l2, dtype=np.uint8)            # r2 junk
+        elif kind < 0.22:
+            t = seqs[rng.integers(0, len(seqs))]; b = t[:l2].copy()  # mate from elsewhere / wrong strand
+        for x in (a, b):
+            m = rng.random(x.shape[0]) < err
+            x[m] = (x[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+            x[rng.random(x.shape[0]) < 0.002] = 4
+        r1[i], r2[i] = a, b
+    return r1, r2
+
+
+def _both(strs, cfg, c1, c2=None):
+    from oracle import oracle
+    index = engine.Index(strs, cfg.k)
+    w1 = synth.pack_codes(c1)
+    kw = {}
+    if c2 is not None:
+        kw = dict(mate_words=synth.pack_codes(c2), mate_max_len=c2.shape[1])
+    gpu = run_gpu(index, cfg, w1, None, c1.shape[1], **kw)
+    b1, o1 = synth.reads_to_ascii(c1)
+    b2, o2 = synth.reads_to_ascii(c2) if c2 is not None else (None, None)
+    ora = oracle.OracleIndex(strs, cfg.k).align(cfg, b1, o1, b2, o2, n_threads=8)
+    return gpu, ora
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(intersect_level=1), dict(intersect_level=2), dict(require_valid_pair=True),
+    dict(strand_filter="fiveprime"), dict(strand_filter="threeprime", intersect_level=1),
+    dict(discard_multiple_matches=True, intersect_level=2), dict(score_filter=120, score_percent=0.8),
+])
+def test_pairs(built, kw):
+    _, seqs, strs, _ = library_strings(4, 8, locus_len=600, seed=31)
+    c1, c2 = synth_pairs(seqs, 3000, 100, 91, seed=5)
+    gpu, ora = _both(strs, engine.make_config(**kw), c1, c2)
+    assert (ora["mates"] == 2).sum() > 500
+    assert_same(gpu, ora, f"pairs {kw}")
+
+
+@pytest.mark.parametrize("M", [1, 2, 5])
+def test_tolerated_mismatches_single_end(built, M):
+    _, seqs, strs, _ = library_strings(3, 4, locus_len=800, seed=8, )
+    codes = synth.synth_reads(seqs, 3000, 150, seed=M, err=0.02, n_rate=0.004)
+    cfg = engine.make_config(num_mismatches=M)
+    gpu, ora = _both(strs, cfg, codes)
+    from oracle import oracle
+    base = oracle.OracleIndex(strs, 20).align(engine.make_config(), *synth.reads_to_ascii(codes), n_threads=8)
+    assert (ora["cov"] > base["cov"]).sum() > 200          # the tolerance actually changes outcomes on this input
+    assert_same(gpu, ora, f"M={M}")
+
+
+def test_tolerated_mismatches_pairs_wide(built):
+    _, seqs, strs, _ = library_strings(70, 70, locus_len=320, seed=12)      # 4900 sequences: multi-word rows
+    c1, c2 = synth_pairs(seqs, 1500, 120, 100, seed=2, frag=300, err=0.015)
+    gpu, ora = _both(strs, engine.make_config(num_mismatches=2, intersect_level=1), c1, c2)
+    assert_same(gpu, ora, "pairs M=2 wide")
+
+
+def test_general_kernel_ragged_pairs(built):
+    """Variable-length mates, including mates shorter than k and empty ones."""
+    from oracle import oracle
+    _, seqs, strs, _ = library_strings(3, 5, locus_len=500, seed=4)
+    rng = np.random.default_rng(6)
+    comp = str.maketrans("ACGT", "TGCA")
+    r1s, r2s = [], []
+    for _ in range(600):
+        a = rng.integers(0, len(strs)); l1, l2 = int(rng.integers(0, 160)), int(rng.integers(0, 130))
+        o = int(rng.integers(0, 500 - 300)); frag = strs[a][o:o + 300]
+        if rng.random() < 0.5: frag = frag.translate(comp)[::-1]
+        r1s.append(frag[:l1]); r2s.append(frag[300 - l2:].translate(comp)[::-1] if l2 else "")
+    w1, n1 = engine.pack_reads(r1s, 160); w2, n2 = engine.pack_reads(r2s, 130)
+    cfg = engine.make_config(num_mismatches=1)
+    gpu = run_gpu(engine.Index(strs, 20), cfg, w1, n1, 160, mate_words=w2, mate_lens=n2, mate_max_len=130)
+    ora = oracle.OracleIndex(strs, 20).align_strs(cfg, r1s, r2s, n_threads=4)
+    assert_same(gpu, ora, "ragged pairs")
