@@ -1,0 +1,135 @@
+"""End to end on the GPU: lib.json + FASTQ -> `align` -> TSV -> `report`, checked against the oracle's calls pushed
+through the same host rules (docs/SPEC.md §5) and, for the reducer, through the golden-pinned report()."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nimble_amd import engine, library, synth
+from nimble_amd.__main__ import main as cli
+from tests.helpers import library_strings
+
+pytestmark = pytest.mark.gpu
+
+
+def write_fastq(path, names, seqs, quals=None):
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "wt") as f:
+        for i, (n, s) in enumerate(zip(names, seqs)):
+            q = quals[i] if quals else "I" * len(s)
+            f.write(f"@{n}\n{s}\n+\n{q}\n")
+
+
+def make_library(tmp_path, n_loci=5, alleles=8, name="hla", group_on="", **cfg):
+    names, seqs, strs, lineage = library_strings(n_loci, alleles, locus_len=600, seed=77)
+    csv_path = tmp_path / f"{name}.csv"
+    with open(csv_path, "w") as f:
+        f.write("name,sequence,lineage\n")
+        for n, s, l in zip(names, strs, lineage):
+            f.write(f"{n},{s},{l}\n")
+    out = tmp_path / f"{name}.json"
+    assert cli(["generate", "--file", str(csv_path), "--output_path", str(out)]) == 0
+    doc = json.load(open(out))
+    doc[0].update(cfg)
+    doc[0]["group_on"] = group_on
+    json.dump(doc, open(out, "w"), indent=2)
+    return out, names, seqs, strs, lineage
+
+
+def expected_bulk(lib_path, reads, strand="unstranded"):
+    from oracle import oracle
+    lib = library.Library(str(lib_path))
+    c = lib.config
+    cfg = engine.make_config(k=lib.k, score_threshold=c["score_threshold"], score_filter=c["score_filter"], score_percent=c["score_percent"],
+                             num_mismatches=c["num_mismatches"], discard_multiple_matches=c["discard_multiple_matches"],
+                             intersect_level=c["intersect_level"], require_valid_pair=c["require_valid_pair"], strand_filter=strand)
+    ora = oracle.OracleIndex(lib.sequences, lib.k).align_strs(cfg, reads, n_threads=4)
+    return lib, ora
+
+
+def test_bulk_single_end(built, tmp_path):
+    lib_path, names, seqs, strs, lineage = make_library(tmp_path, max_hits_to_report=4)
+    codes = synth.synth_reads(seqs, 4000, 120, seed=3)
+    reads = [synth.codes_to_str(c) for c in codes]
+    fq = tmp_path / "reads.fastq.gz"
+    write_fastq(fq, [f"r{i}" for i in range(len(reads))], reads)
+    out = tmp_path / "out.tsv"
+    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(fq)]) == 0
+    lib, ora = expected_bulk(lib_path, reads)
+    want = {}
+    for i in np.nonzero(ora["reason"] == 0)[0]:
+        feats = lib.feature_list(engine.bits_to_members(ora["set_bits"][i]))
+        if len(feats) <= 4:
+            k = ",".join(feats); want[k] = want.get(k, 0) + 1
+    lines = open(out).read().splitlines()
+    assert lines[0] == "nimble_features\tnimble_score"
+    got = {l.split("\t")[0]: int(l.split("\t")[1]) for l in lines[1:]}
+    assert got == want and [l.split("\t")[0] for l in lines[1:]] == sorted(want)
+
+
+def test_two_libraries_group_on_and_naming(built, tmp_path):
+    """Several -r libraries in one pass: outputs named with append_path_string (__main__.py:182-189); group_on."""
+    a, *_ = make_library(tmp_path, name="mhc_a")
+    b, names, seqs, strs, lineage = make_library(tmp_path, name="mhc_b", group_on="lineage", discard_multi_hits=1)
+    codes = synth.synth_reads(seqs, 2000, 150, seed=9)
+    reads = [synth.codes_to_str(c) for c in codes]
+    fq = tmp_path / "reads.fastq"
+    write_fastq(fq, [f"r{i}" for i in range(len(reads))], reads)
+    out = tmp_path / "res.tsv.gz"
+    assert cli(["align", "--reference", f"{a},{b}", "--output", str(out), "--input", str(fq), "--strand_filter", "none"]) == 0
+    assert os.path.exists(tmp_path / "res.mhc_a.tsv.gz") and os.path.exists(tmp_path / "res.mhc_b.tsv.gz")
+    lib, ora = expected_bulk(b, reads, "none")
+    want = {}
+    for i in np.nonzero(ora["reason"] == 0)[0]:
+        feats = lib.feature_list(engine.bits_to_members(ora["set_bits"][i]))
+        if len(feats) <= 1:
+            want[feats[0]] = want.get(feats[0], 0) + 1
+    lines = gzip.open(tmp_path / "res.mhc_b.tsv.gz", "rt").read().splitlines()[1:]
+    assert {l.split("\t")[0]: int(l.split("\t")[1]) for l in lines} == want and set(want) <= set(lineage)
+
+
+def test_tenx_per_read_rows_then_report(built, tmp_path):
+    lib_path, names, seqs, strs, lineage = make_library(tmp_path)
+    rng = np.random.default_rng(5)
+    n = 3000
+    codes = synth.synth_reads(seqs, n, 91, seed=4)
+    r2 = [synth.codes_to_str(c) for c in codes]
+    wl = ["".join("ACGT"[c] for c in rng.integers(0, 4, 16)) for _ in range(40)]
+    cells = [wl[i] for i in rng.integers(0, 8, n)]
+    umis = ["".join("ACGT"[c] for c in rng.integers(0, 4, 12)) for _ in range(n // 4)]
+    umi_of = [umis[i] for i in rng.integers(0, len(umis), n)]
+    raw_cb = []
+    for c in cells:
+        if rng.random() < 0.05:
+            j = int(rng.integers(0, 16)); c = c[:j] + "ACGT"[("ACGT".index(c[j]) + 1) % 4] + c[j + 1:]
+        raw_cb.append(c)
+    r1 = [c + u + "TTTTTTTT" for c, u in zip(raw_cb, umi_of)]
+    (tmp_path / "wl.txt").write_text("\n".join(wl) + "\n")
+    write_fastq(tmp_path / "R1.fastq.gz", [f"q{i}/1" for i in range(n)], r1)
+    write_fastq(tmp_path / "R2.fastq.gz", [f"q{i}/2" for i in range(n)], r2)
+    out = tmp_path / "per_read.tsv"
+    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(tmp_path / "R1.fastq.gz"),
+                str(tmp_path / "R2.fastq.gz"), "--tenx", "--map", str(tmp_path / "wl.txt")]) == 0
+    lib, ora = expected_bulk(lib_path, r2)
+    from nimble_amd import barcodes
+    corr = barcodes.BarcodeCorrector(set(wl))
+    want = []
+    for i in range(n):
+        cb = corr.correct(raw_cb[i], "I" * 16)
+        if ora["reason"][i] == 0 and cb is not None:
+            feats = lib.feature_list(engine.bits_to_members(ora["set_bits"][i]))
+            if len(feats) <= 10:
+                want.append("\t".join([",".join(feats), "1", cb, umi_of[i]] + [str(x) for x in ora["cov"][i]]))
+    lines = open(out).read().splitlines()
+    assert lines[0].split("\t")[:4] == ["nimble_features", "nimble_score", "r1_CB", "r1_UB"]
+    assert lines[1:] == want and len(want) > 1000
+    # reducer on the per-read table: equal to feeding the expected rows through the golden-pinned report()
+    from nimble_amd.report import report
+    (tmp_path / "exp.tsv").write_text("\n".join([lines[0]] + want) + "\n")
+    assert cli(["report", "-i", str(out), "-o", str(tmp_path / "counts.tsv")]) == 0
+    report(str(tmp_path / "exp.tsv"), str(tmp_path / "counts_exp.tsv"))
+    got = open(tmp_path / "counts.tsv").read()
+    assert got == open(tmp_path / "counts_exp.tsv").read() and len(got.splitlines()) > 5
+    assert all(len(l.split("\t")) == 3 for l in got.splitlines())
