@@ -303,6 +303,99 @@ __device__ __forceinline__ void map_both_strands(const DevIndex& ix, const uint6
   }
 }
 
+// Fast-path twin of map_both_strands for the hot kernel: the whole packed record is fetched with wave-uniform loads
+// first (one round trip), every round's k-mer is prepared, then the table probes of ALL rounds are issued together
+// and collisions are resolved in lock-step, so a read costs ~1-2 dependent memory round trips here instead of 3+ per
+// round. Same results as map_both_strands (tests compare both kernels against the oracle).
+template <int NR>
+__device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int lane,
+                                                      Strand<NR>& F, Strand<NR>& R) {
+  constexpr int NWB = 2 * NR + 1, NWN = NR + 1;
+  const int K = ix.K, P = L - K + 1, nwn = (nwb + 1) >> 1;
+  uint64_t w[NWB + 1], nm[NWN + 1];
+#pragma unroll
+  for (int j = 0; j < NWB; ++j) w[j] = (j < nwb) ? rp[j] : 0ull;
+  w[NWB] = 0;
+#pragma unroll
+  for (int j = 0; j < NWN; ++j) nm[j] = (j < nwn) ? rp[nwb + j] : 0ull;
+  nm[NWN] = 0;
+  const bool hiHalf = lane >= 32;
+  const int sh = (lane & 31) * 2;
+  const uint64_t kmask = (1ull << (2 * K)) - 1, nkmask = (1ull << K) - 1;
+  const uint64_t smask = (1ull << ix.cap_log2) - 1;
+  uint64_t canon[NR]; uint64_t hh[NR]; uint32_t meta[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = lane + 64 * r;
+    const uint64_t lo = hiHalf ? w[2 * r + 1] : w[2 * r], hi = hiHalf ? w[2 * r + 2] : w[2 * r + 1];
+    const uint64_t win = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    const uint64_t nlo = nm[r], nhi = nm[r + 1];
+    const uint64_t nwin = lane ? ((nlo >> lane) | (nhi << (64 - lane))) : nlo;
+    const bool validk = (i < P) && ((nwin & nkmask) == 0);
+    const uint64_t x = win & kmask;
+    const bool next_ok = (i + K < L) && !((nwin >> K) & 1);
+    const uint32_t nextb = (uint32_t)(win >> (2 * K)) & 3u;
+    uint32_t prevb; bool prevN;
+    if (lane & 31) prevb = (uint32_t)(lo >> (sh - 2)) & 3u;
+    else prevb = (uint32_t)((hiHalf ? w[2 * r] : (r ? w[2 * r - 1 < 0 ? 0 : 2 * r - 1] : 0ull)) >> 62) & 3u;
+    if (lane) prevN = (nlo >> (lane - 1)) & 1;
+    else prevN = r ? ((nm[r - 1 < 0 ? 0 : r - 1] >> 63) & 1) : false;
+    const bool prev_ok = (i >= 1) && !prevN;
+    const uint64_t y = rc_kmer(x, K);
+    const uint64_t c = x < y ? x : y;
+    canon[r] = c;
+    hh[r] = (c * HASH_MULT) >> (64 - ix.cap_log2);
+    meta[r] = (validk ? 1u : 0u) | ((x != c) ? 2u : 0u) | (next_ok ? 4u : 0u) | (nextb << 3) | (prev_ok ? 32u : 0u) | (prevb << 6);
+  }
+  uint32_t payF[NR], payR[NR]; bool pend[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { payF[r] = PAY_ABSENT; payR[r] = PAY_ABSENT; pend[r] = meta[r] & 1u; }
+  for (;;) {
+    // unconditional loads (idle lanes read slot 0) so that all NR probes are in flight together: no exec-masked branch
+    uint4 raw[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) raw[r] = *reinterpret_cast<const uint4*>(&ix.slots[pend[r] ? hh[r] : 0ull]);
+    bool more = false;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const uint64_t key = ((uint64_t)raw[r].y << 32) | raw[r].x;
+      const bool hit = pend[r] && key == canon[r], stop = key == SLOT_EMPTY;
+      const bool o = meta[r] & 2u;
+      payF[r] = hit ? (o ? raw[r].w : raw[r].z) : payF[r];
+      payR[r] = hit ? (o ? raw[r].z : raw[r].w) : payR[r];
+      pend[r] = pend[r] && !hit && !stop;
+      hh[r] = (hh[r] + 1) & smask;
+      more |= pend[r];
+    }
+    if (__ballot(more) == 0) break;
+  }
+  Mask<NR> HF, RF, LF, HR, RR, LR;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
+    const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
+    const bool hF = payF[r] != PAY_ABSENT, hR = payR[r] != PAY_ABSENT;
+    F.col[r] = payF[r] >> 10; R.col[r] = payR[r] >> 10;
+    HF.w[r] = __ballot(hF);
+    RF.w[r] = __ballot(hF && next_ok && ((payF[r] >> nextb) & 1u));
+    LF.w[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
+    HR.w[r] = __ballot(hR);
+    RR.w[r] = __ballot(hR && prev_ok && ((payR[r] >> (3u - prevb)) & 1u));
+    LR.w[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
+  }
+  F.cov = any_set<NR>(HF) ? walk_masks<NR>(HF, RF, LF, L, K, F.V) : 0;
+  if (any_set<NR>(HR)) {
+    const Mask<NR> h = reverse_mask<NR>(HR, P), rr = reverse_mask<NR>(RR, P), l = reverse_mask<NR>(LR, P);
+    Mask<NR> v;
+    R.cov = walk_masks<NR>(h, rr, l, L, K, v);
+    R.V = reverse_mask<NR>(v, P);
+  } else {
+    R.cov = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) R.V.w[r] = 0;
+  }
+}
+
 // Step 4: eq = AND of the colour rows of the visited positions. acc[t] (lane l) = word l + 64 t. Returns |eq|.
 template <int NR, int TW>
 __device__ __forceinline__ uint32_t intersect_visited(const DevIndex& ix, const Strand<NR>& S, int lane, uint64_t (&acc)[TW]) {
@@ -319,9 +412,14 @@ __device__ __forceinline__ uint32_t intersect_visited(const DevIndex& ix, const 
     while (z) {
       const int wl = __builtin_ctzll(z); z &= z - 1;
       const int wi = 64 * t + wl;
-      uint64_t v = ~0ull;
+      // branch-free gather: lanes that visited nothing in round r re-read the seed row's word (a no-op for the AND),
+      // so all NR loads are in flight together
+      uint64_t g[NR];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) if ((S.V.w[r] >> lane) & 1) v &= ix.eq[(size_t)S.col[r] * W + wi];
+      for (int r = 0; r < NR; ++r) g[r] = ix.eq[(size_t)(((S.V.w[r] >> lane) & 1) ? S.col[r] : seed) * W + wi];
+      uint64_t v = g[0];
+#pragma unroll
+      for (int r = 1; r < NR; ++r) v &= g[r];
       v = wave_and_u64(v);
       if (lane == wl) acc[t] = v;
     }
@@ -343,9 +441,12 @@ __device__ __forceinline__ uint32_t intern_class(const DevClasses& ct, int W, in
   const uint64_t smask = (1ull << ct.cap_log2) - 1;
   uint64_t h = (key * HASH_MULT) >> (64 - ct.cap_log2);
   for (uint64_t probes = 0; probes <= smask; ++probes, h = (h + 1) & smask) {
-    uint64_t cur = 0;
-    if (lane == 0) cur = __hip_atomic_load(&ct.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cur = bcast_u64(cur);
+    uint64_t cur = 0; uint32_t idp = 0;
+    if (lane == 0) {   // key and id word fetched together: one round trip on the common (already interned) path
+      cur = __hip_atomic_load(&ct.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      idp = __hip_atomic_load(&ct.ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    cur = bcast_u64(cur); idp = __builtin_amdgcn_readfirstlane(idp);
     if (cur == 0) {
       if (lane == 0) { unsigned long long expected = 0ull;
         __hip_atomic_compare_exchange_strong(&ct.keys[h], &expected, (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -369,12 +470,10 @@ __device__ __forceinline__ uint32_t intern_class(const DevClasses& ct, int W, in
       }
     }
     if (cur == key) {
-      uint32_t idp = 0;
-      for (int spin = 0; spin < (1 << 22); ++spin) {
+      for (int spin = 0; idp == 0 && spin < (1 << 22); ++spin) {   // the owner is still publishing: poll
+        __builtin_amdgcn_s_sleep(8);
         if (lane == 0) idp = __hip_atomic_load(&ct.ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         idp = __builtin_amdgcn_readfirstlane(idp);
-        if (idp != 0) break;
-        __builtin_amdgcn_s_sleep(8);
       }
       if (idp == 0) { if (lane == 0) atomicOr(ct.err, 2u); return NB_NO_CLASS; }
       if (idp == 0xFFFFFFFFu) return NB_NO_CLASS;
@@ -402,7 +501,7 @@ __device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) 
 // ------------------------------------------------------------------------------------------------------------
 // single-end kernel: one read per wave, grid-stride over the batch.
 template <int NR, int TW>
-__global__ __launch_bounds__(256) void nb_align_se_kernel(DevIndex ix, DevClasses ct, BatchArgs a) {
+__global__ __launch_bounds__(256) void nb_align_se_kernel(DevIndex ix, DevClasses ct, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   __syncthreads();
@@ -414,9 +513,9 @@ __global__ __launch_bounds__(256) void nb_align_se_kernel(DevIndex ix, DevClasse
     if (L > a.max_len) L = a.max_len;   // never index past the packed record
     int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0; uint32_t cls = NB_NO_CLASS; int covF = 0, covR = 0;
     if (L >= ix.K) {
-      const uint64_t* rp = a.reads + (size_t)r * a.stride;
-      Strand<NR> SF, SR;
-      map_both_strands<NR>(ix, rp, a.nwb, L, lane, SF, SR);
+      const uint64_t* __restrict__ rp = reads_ro + (size_t)r * a.stride;   // separate noalias kernel argument: lets the
+      Strand<NR> SF, SR;                                                    // compiler fetch the record with scalar loads
+      map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR);
       covF = SF.cov; covR = SR.cov;
       // candidates in preference order: larger coverage first, tie -> F   (SPEC §4 "Chosen orientation")
       const bool first_is_R = covR > covF;
@@ -732,7 +831,7 @@ static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStrea
   const long long cap = (long long)c->n_cu * 8;   // 8 blocks of 4 waves per CU = 32 waves/CU
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
+  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a, a.reads);
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
