@@ -33,6 +33,7 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread",
            "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH] + srcs + ["-lz"]
+    cmd[1:1] = os.environ.get("NB_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DNB_SE_WAVES_PER_EU=8 for tuning experiments
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

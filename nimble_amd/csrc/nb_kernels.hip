@@ -354,7 +354,11 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
     // unconditional loads (idle lanes read slot 0) so that all NR probes are in flight together: no exec-masked branch
     uint4 raw[NR];
 #pragma unroll
+#if defined(NB_ABLATE) && NB_ABLATE == 3
+    for (int r = 0; r < NR; ++r) { raw[r].x = (uint32_t)canon[r]; raw[r].y = (uint32_t)(canon[r] >> 32); raw[r].z = (uint32_t)hh[r] << 10 | 0xFF; raw[r].w = PAY_ABSENT; }  // timing-only: no table loads, every k-mer "hits"
+#else
     for (int r = 0; r < NR; ++r) raw[r] = *reinterpret_cast<const uint4*>(&ix.slots[pend[r] ? hh[r] : 0ull]);
+#endif
     bool more = false;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -500,8 +504,11 @@ __device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) 
 
 // ------------------------------------------------------------------------------------------------------------
 // single-end kernel: one read per wave, grid-stride over the batch.
+#ifndef NB_SE_WAVES_PER_EU
+#define NB_SE_WAVES_PER_EU 1, 6   // measured on MI355X (10M x 150bp, 1k seqs): 6 waves/SIMD 23.4 ms, 7 -> 28.1, 8 -> 25.5:
+#endif                             // the kernel is bound by L2-miss request rate, more waves only thrash L2
 template <int NR, int TW>
-__global__ __launch_bounds__(256) void nb_align_se_kernel(DevIndex ix, DevClasses ct, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ct, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   __syncthreads();
@@ -526,7 +533,11 @@ __global__ __launch_bounds__(256) void nb_align_se_kernel(DevIndex ix, DevClasse
         const int cov = isR ? covR : covF;
         int rs = cheap_reason(cov, L, a);
         if (rs == 0) {
+#if defined(NB_ABLATE) && NB_ABLATE >= 2
+          acc[0] = (uint64_t)(isR ? SR.col[0] : SF.col[0]); const uint32_t n = 1;   // timing-only build: no intersection
+#else
           const uint32_t n = isR ? intersect_visited<NR, TW>(ix, SR, lane, acc) : intersect_visited<NR, TW>(ix, SF, lane, acc);
+#endif
           if (n == 0) rs = NB_EMPTY_EQCLASS;
           else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
           else if ((isR && a.strand_filter == NB_STRAND_FIVEPRIME) || (!isR && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
@@ -538,8 +549,12 @@ __global__ __launch_bounds__(256) void nb_align_se_kernel(DevIndex ix, DevClasse
         if (score < a.score_filter) reason = NB_SCORE_FILTER;
         else {
           reason = NB_CALLED;
+#if defined(NB_ABLATE) && NB_ABLATE >= 1
+          cls = (uint32_t)acc[0] & 1u;   // timing-only build: no interning, no counting
+#else
           cls = intern_class<TW>(ct, ix.W, lane, acc);
           if (cls != NB_NO_CLASS && lane == 0) atomicAdd(&ct.counts[cls], 1ull);
+#endif
         }
       } else reason = reasons[0] > reasons[1] ? reasons[0] : reasons[1];
     }
