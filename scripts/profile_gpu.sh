@@ -1,22 +1,22 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun) from the repo root: bench line + rocprofv3 kernel stats + HBM traffic counters.
-# Outputs under gpurun_out/<tag>/; copy the summaries you want judged into profiles/.
+# Run ON THE GPU BOX (via gpurun) from the repo root: bench line + rocprofv3 kernel stats + PMC passes for one config.
+#   bash scripts/profile_gpu.sh <tag> <config c2|c3|c5> [steps]
+# Outputs under gpurun_out/<tag>/; summary.txt and traffic.json are what gets copied into profiles/.
 set -e
-TAG=${1:-r01}
-READS=${2:-10000000}
+TAG=${1:-r01}; CFG=${2:-c2}; STEPS=${3:-5}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 echo "== bench (unprofiled) =="
-python bench.py --steps 5 --warmup 1 --reads $READS > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
-cat "$OUT/bench.json"
+python bench.py --config $CFG --steps $STEPS --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
+cut -c1-400 "$OUT/bench.json"
+Q="--config $CFG --warmup 1 --no-cpu-baseline --parity-sample 0"
 echo "== rocprofv3 kernel trace + stats =="
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps 5 --warmup 1 --reads $READS --no-cpu-baseline --parity-sample 0 > "$OUT/trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
-echo "== rocprofv3 PMC: FETCH_SIZE =="
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- python3 bench.py --steps 2 --warmup 1 --reads $READS --no-cpu-baseline --parity-sample 0 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || { tail -5 "$OUT/pmc_fetch.err"; exit 1; }
-echo "== rocprofv3 PMC: WRITE_SIZE =="
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- python3 bench.py --steps 2 --warmup 1 --reads $READS --no-cpu-baseline --parity-sample 0 > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err" || { tail -5 "$OUT/pmc_write.err"; exit 1; }
-echo "== rocprofv3 PMC: L2 hit/miss =="
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -o bench -- python3 bench.py --steps 2 --warmup 1 --reads $READS --no-cpu-baseline --parity-sample 0 > "$OUT/pmc_l2.json" 2> "$OUT/pmc_l2.err" || { tail -5 "$OUT/pmc_l2.err"; exit 1; }
-python scripts/summarize_profile.py "$OUT" > "$OUT/summary.txt"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps $STEPS $Q > "$OUT/trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
+for pass in "pmc_fetch FETCH_SIZE" "pmc_write WRITE_SIZE" "pmc_l2 TCC_HIT_sum TCC_MISS_sum"; do
+  set -- $pass; name=$1; shift
+  echo "== rocprofv3 PMC: $* =="
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o bench -- python3 bench.py --steps 2 $Q > "$OUT/$name.json" 2> "$OUT/$name.err" || { tail -5 "$OUT/$name.err"; exit 1; }
+done
+python scripts/summarize_profile.py "$OUT" "$CFG" > "$OUT/summary.txt"
 cat "$OUT/summary.txt"

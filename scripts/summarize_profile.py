@@ -11,14 +11,18 @@ def find(d, pat):
     return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
 
 
-def main(out):
-    print(f"# rocprofv3 summary for {os.path.basename(out)}")
+def main(out, cfg="c2"):
+    print(f"# rocprofv3 summary for {os.path.basename(out)} (bench.py --config {cfg})")
+    traffic = {"config": cfg}
     for name in ("bench.json", "trace.json"):
         p = os.path.join(out, name)
         if os.path.exists(p) and os.path.getsize(p):
             line = open(p).read().strip().splitlines()[-1]
             try:
                 j = json.loads(line)
+                if name == "bench.json":
+                    traffic.update(reads_per_gpu=j["config"]["reads_per_gpu"], read_len=j["config"]["read_len"], n_seqs=j["config"]["n_seqs"],
+                                   k=j["config"]["k"], kernel=j["roofline"]["kernel"], kernel_ms_avg=j["roofline"]["kernel_ms_avg"])
                 print(f"{name}: value={j['value']:.2f} {j['unit']} ms_per_step={j['ms_per_step']:.3f} kernel_ms_avg={j['roofline']['kernel_ms_avg']:.3f} "
                       f"achieved={j['roofline']['achieved']:.2f} GB/s frac={j['roofline']['frac']:.5f}")
             except Exception as e:  # noqa: BLE001
@@ -41,7 +45,17 @@ def main(out):
                 agg.setdefault(key, []).append(float(r["Counter_Value"]))
             for (k, c), v in agg.items():
                 print(f"{k} {c}: dispatches={len(v)} mean={sum(v) / len(v):.1f} min={min(v):.1f} max={max(v):.1f}")
+                traffic[c] = sum(v) / len(v)
+    if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
+        # rocprofv3 reports both in KB per dispatch. FETCH_SIZE = TCC_EA0_RDREQ x 64 B (guide, MI355X_MICROARCH §HBM): for this
+        # kernel's scattered 16-B probes / 8-B gathers each request is one 64-B fabric read, so no x2 streaming correction is
+        # applied; the x2 figure is kept as an upper bound. Infinity-Cache hits are counted, so this is L2<->fabric traffic.
+        traffic["traffic_bytes_per_launch"] = (traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"]) * 1024
+        traffic["traffic_bytes_per_launch_upper_x2_fetch"] = (2 * traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"]) * 1024
+        print(f"\ntraffic per launch: {traffic['traffic_bytes_per_launch'] / 1e9:.2f} GB (fetch as reported) .. "
+              f"{traffic['traffic_bytes_per_launch_upper_x2_fetch'] / 1e9:.2f} GB (x2 fetch upper bound)")
+    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])
