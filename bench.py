@@ -165,13 +165,27 @@ def main():
                    "sample": f"first {nc} reads of the same batch, {dt:.1f} s wall, alignment only (oracle index build {t_oidx:.1f} s not counted); "
                              "C++ restatement of docs/SPEC.md, not the Rust nimble-aligner"}
 
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
+    # from the committed rocprofv3 PMC passes of the SAME workload (scripts/profile_gpu.sh -> profiles/*_traffic.json).
+    traffic, traffic_src = None, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if (t.get("reads_per_gpu"), t.get("read_len"), t.get("n_seqs"), t.get("k")) == (n, L, len(strs), args.k) and "traffic_bytes_per_launch" in t:
+            traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.basename(f)
+
     line = {
         "metric": "M reads/s aligned (150bp, 1k-seq HLA lib)" if args.config == "c2" else f"M reads/s aligned ({args.config})", "value": value, "unit": "M reads/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{n} x {L}bp single-end reads per GPU vs {len(strs)}-seq HLA-like library; BASELINE {preset['what']}; k={args.k}",
                    "reads_per_gpu": n, "read_len": L, "n_seqs": len(strs), "k": args.k, "parallelism": f"reads sharded x{world}, index replicated"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                     "traffic_note": (f"bytes per launch, (FETCH_SIZE + WRITE_SIZE) KB from {traffic_src}: L2<->fabric requests, mostly served by the "
+                                      "Infinity Cache; algorithmic bytes per launch = " + str(bytes_per_read * n)) if traffic else None,
                      "kernel": engine._lib.lib().nb_kernel_name(L, args.k, len(strs), 0).decode(), "kernel_ms_avg": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_read": bytes_per_read},
         "cpu_baseline": cpu,
