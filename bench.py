@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=20_000)
+    ap.add_argument("--backend", default=os.environ.get("NB_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 logic on a 1-GPU box)")
     args = ap.parse_args()
     preset = PRESETS[args.config]
     for key in ("reads", "read_len", "loci", "alleles"):
@@ -59,13 +61,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank %= max(1, torch.cuda.device_count())     # gloo rehearsal: several ranks may share the one GPU of a dev box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective buffers live
 
     # ---- library + index (identical on every rank) ----
     t0 = time.time()
@@ -110,13 +117,13 @@ def main():
         b.record(stream)
     torch.cuda.synchronize()
     rows, counts = ctx.classes()
-    glob_rows, glob_counts = distributed.reduce_class_counts(rows, counts, device=dev)
+    glob_rows, glob_counts = distributed.reduce_class_counts(rows, counts, device=cdev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = [a.elapsed_time(b) for a, b in evs]

@@ -53,7 +53,16 @@ def test_two_rank_reduce():
     want = {1: 20, 3: 41, 5: 13, 7: 2, 9: 30}
     got = {tuple(r): c for r, c in zip(rows0, c0)}
     assert got == {tuple(int(x) for x in _rows([i])[0]): v for i, v in want.items()}
-    assert rows0 == sorted(rows0)                                         # canonical (lexicographic) dictionary order
+
+
+def test_agree_hash_path_equals_exact_path():
+    rng = np.random.default_rng(3)
+    base = rng.integers(-2**62, 2**62, size=(300, 5))
+    R = torch.from_numpy(np.concatenate([base, base[:120], base[50:70]]))
+    g1, i1 = distributed._agree(R, use_hash=True)
+    g2, i2 = distributed._agree(R, use_hash=False)
+    assert g1.shape == g2.shape == (300, 5) and bool((g1[i1] == R).all()) and bool((g2[i2] == R).all())
+    assert {tuple(r) for r in g1.tolist()} == {tuple(r) for r in g2.tolist()}
 
 
 def test_single_rank_identity():
