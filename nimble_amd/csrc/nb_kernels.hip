@@ -56,33 +56,54 @@ struct BatchArgs {
 
 // ------------------------------------------------------------------------------------------------------------
 // wave-level helpers (wave64)
+// Wave-wide reductions with a wave-UNIFORM result: four DPP row rotations reduce inside each row of 16 lanes (every
+// lane of a row ends up with the row's value), then four v_readlane + scalar ops combine the rows. No LDS traffic
+// (ds_bpermute) and no lgkmcnt waits. Must be called with all 64 lanes active (wave-uniform control flow).
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+  // old = the source itself: with every lane enabled `old` is never selected, but passing 0 lets hipcc's DPP-combine fold
+  // it into v_min_u32_dpp with a wrong identity (observed on ROCm 7.2: wave_min returned 0)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+// NOTE each DPP move is evaluated ONCE into a temporary before the combining op: writing `cond ? dpp(v) : v` makes hipcc
+// re-issue the DPP move inside a divergent branch (partial EXEC), which reads stale lanes.
+struct OpMin { __device__ __forceinline__ static uint32_t f(uint32_t a, uint32_t b) { return a < b ? a : b; } };
+struct OpAnd { __device__ __forceinline__ static uint32_t f(uint32_t a, uint32_t b) { return a & b; } };
+struct OpAdd { __device__ __forceinline__ static uint32_t f(uint32_t a, uint32_t b) { return a + b; } };
+template <class OP> __device__ __forceinline__ uint32_t row_reduce(uint32_t v) {
+  uint32_t t;
+  t = dpp_mov<0x121>(v); v = OP::f(v, t);
+  t = dpp_mov<0x122>(v); v = OP::f(v, t);
+  t = dpp_mov<0x124>(v); v = OP::f(v, t);
+  t = dpp_mov<0x128>(v); v = OP::f(v, t);
+  return v;
+}
+#define NB_ROW_REDUCE(v, OP) v = row_reduce<OP>(v)
+#define NB_OP_MIN OpMin
+#define NB_OP_AND OpAnd
+#define NB_OP_ADD OpAdd
+__device__ __forceinline__ uint32_t rows4(uint32_t v, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 16 * k); }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = t < v ? t : v; }
-  return v;
+  NB_ROW_REDUCE(v, NB_OP_MIN);
+  const uint32_t a = rows4(v, 0), b = rows4(v, 1), c = rows4(v, 2), d = rows4(v, 3);
+  const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
 }
-__device__ __forceinline__ uint64_t wave_and_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
-    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-    v &= ((uint64_t)hi << 32) | lo;
-  }
-  return v;
-}
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
-    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-    v += ((uint64_t)hi << 32) | lo;
-  }
-  return v;
+__device__ __forceinline__ uint32_t wave_and_u32(uint32_t v) {
+  NB_ROW_REDUCE(v, NB_OP_AND);
+  return rows4(v, 0) & rows4(v, 1) & rows4(v, 2) & rows4(v, 3);
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-  return v;
+  NB_ROW_REDUCE(v, NB_OP_ADD);
+  return rows4(v, 0) + rows4(v, 1) + rows4(v, 2) + rows4(v, 3);
+}
+__device__ __forceinline__ uint64_t wave_and_u64(uint64_t v) {
+  return ((uint64_t)wave_and_u32((uint32_t)(v >> 32)) << 32) | wave_and_u32((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {   // mod 2^64: sum the halves separately, carry by hand
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  // low halves: 64 values < 2^32 sum to < 2^38: split into 16-bit limbs so 32-bit lane adds cannot overflow
+  const uint32_t s0 = wave_sum_u32(lo & 0xFFFFu), s1 = wave_sum_u32(lo >> 16), s2 = wave_sum_u32(hi & 0xFFFFu), s3 = wave_sum_u32(hi >> 16);
+  return (uint64_t)s0 + ((uint64_t)s1 << 16) + ((uint64_t)s2 << 32) + ((uint64_t)s3 << 48);
 }
 __device__ __forceinline__ uint64_t bcast_u64(uint64_t v) {  // lane 0's value to every lane
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -209,6 +230,52 @@ __device__ __forceinline__ int walk_masks(const Mask<NR>& H, const Mask<NR>& R, 
     if (b > last) break;
     p = ffs_stride3<NR>(H, b);
     if (p < 0) break;
+  }
+  return cov;
+}
+
+// highest set bit at a position i <= from with (from - i) % 3 == 0, or -1
+template <int NR> __device__ __forceinline__ int fls_stride3_down(const Mask<NR>& m, int from) {
+  const uint64_t PAT = 0x9249249249249249ull;
+#pragma unroll
+  for (int wi = NR - 1; wi >= 0; --wi) {
+    const int base = wi * 64;
+    if (from >= base) {
+      uint64_t v = m.w[wi];
+      const int res = ((from % 3) - (wi % 3) + 3) % 3;
+      v &= PAT << res;
+      if (from < base + 63) v &= (2ull << (from - base)) - 1;
+      if (v) return base + 63 - __builtin_clzll(v);
+    }
+  }
+  return -1;
+}
+
+// SPEC §3 for the REVERSE-COMPLEMENT strand, evaluated directly on masks indexed by read position i (rc position
+// j = P-1-i): the walk advances towards lower i, "left" is towards higher i. Same arithmetic as walk_masks on the
+// bit-reversed masks, without reversing them. H/R/LX are the rc strand's facts at read position i.
+template <int NR>
+__device__ __forceinline__ int walk_masks_down(const Mask<NR>& H, const Mask<NR>& R, const Mask<NR>& LX, int L, int K, Mask<NR>& V) {
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) V.w[wi] = 0;
+  const int last = L - K;                       // = P-1
+  int ip = fls_stride3_down<NR>(H, last);       // rc position 0 is read position last
+  if (ip < 0) return 0;
+  int cov = 0;
+  const int pj = last - ip;
+  if (pj >= L / 5 && pj > 0) {                  // left extension: consecutive LX bits going UP from ip
+    const int z = ffz_from<NR>(LX, ip);
+    const int t = z - ip;
+    if (t > 0) { cov += t; set_range<NR>(V, ip + 1, ip + t); }
+  }
+  for (;;) {
+    const int ei = flz_upto<NR>(R, ip);         // run ip .. ei (downwards)
+    cov += K + (ip - ei);
+    set_range<NR>(V, ei, ip);
+    const int bj = (last - ei) + K;
+    if (bj > last) break;
+    ip = fls_stride3_down<NR>(H, last - bj);
+    if (ip < 0) break;
   }
   return cov;
 }
@@ -389,10 +456,7 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
   }
   F.cov = any_set<NR>(HF) ? walk_masks<NR>(HF, RF, LF, L, K, F.V) : 0;
   if (any_set<NR>(HR)) {
-    const Mask<NR> h = reverse_mask<NR>(HR, P), rr = reverse_mask<NR>(RR, P), l = reverse_mask<NR>(LR, P);
-    Mask<NR> v;
-    R.cov = walk_masks<NR>(h, rr, l, L, K, v);
-    R.V = reverse_mask<NR>(v, P);
+    R.cov = walk_masks_down<NR>(HR, RR, LR, L, K, R.V);
   } else {
     R.cov = 0;
 #pragma unroll
