@@ -135,6 +135,13 @@ int32_t nb_fastq_close(nb_fastq* fq);
 int32_t nb_fastq_next_batch(nb_fastq* fq, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
                             int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len, char* cbqual_out);
 
+/* ---- `nimble report` reducer (host, no GPU needed): per-read TSV -> feature<TAB>count<TAB>cell_barcode.
+ * Replaces /root/reference/nimble/__main__.py:254-302 + nimble/utils.py:119-224 for large tables; byte-identical output
+ * (same golden fixtures as nimble_amd/report.py). status_out[0] = 1 if the empty output was written, status_out[1] =
+ * number of UMIs dropped for an empty intersection. ---- */
+int32_t nb_report_tsv(const char* input_path, const char* output_path, double threshold, int32_t disable_thresholding,
+                      int64_t* status_out);
+
 /* name of the kernel nb_align_batch launches for this shape (for matching rocprofv3 kernel-trace rows) */
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired);
 

@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnimble_amd.so")
-SOURCES = ["nb_kernels.hip", "nb_index.cpp", "nb_ingest.cpp"]
+SOURCES = ["nb_kernels.hip", "nb_index.cpp", "nb_ingest.cpp", "nb_report.cpp"]
 HEADERS = [os.path.join(CSRC, "nb_internal.h"), os.path.join(REPO_ROOT, "include", "nimble_amd.h")]
 
 
@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread",
+    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
            "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH] + srcs + ["-lz"]
     cmd[1:1] = os.environ.get("NB_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DNB_SE_WAVES_PER_EU=8 for tuning experiments
     if verbose:

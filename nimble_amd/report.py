@@ -134,8 +134,26 @@ def filter_umi_features(group, threshold):
             return set()
 
 
-def report(input, output, summarize_columns_list=None, threshold=0.05, disable_thresholding=False):
-    """Same signature and output as the reference's report() (__main__.py:254)."""
+def report_native(input, output, threshold=0.05, disable_thresholding=False):
+    """The same reduction in C++ (csrc/nb_report.cpp, nb_report_tsv): for 10^7..10^8-row tables."""
+    import ctypes as ct
+    from . import _lib
+    st = (ct.c_int64 * 2)()
+    _lib.check(_lib.lib().nb_report_tsv(os.fsencode(input), os.fsencode(output), float(threshold), int(bool(disable_thresholding)), st))
+    if st[0]:
+        print("No data to parse from input file, writing empty output.")
+    else:
+        print(f"Dropped {st[1]} UMIs due to empty intersections")
+
+
+def report(input, output, summarize_columns_list=None, threshold=0.05, disable_thresholding=False, engine=None):
+    """Same signature and output as the reference's report() (__main__.py:254). `engine`: "python" (this module) or
+    "native" (nb_report_tsv); default from $NIMBLE_REPORT_ENGINE, else native. Both are pinned by the same fixtures."""
+    engine = engine or os.environ.get("NIMBLE_REPORT_ENGINE", "native")
+    if summarize_columns_list:
+        raise NotImplementedError("report -s/--summarize (reference __main__.py:307-310) is outside the hot-path scope of this build")
+    if engine == "native":
+        return report_native(input, output, threshold, disable_thresholding)
     rows = read_rows(input)
     if rows is None:
         write_empty(output)

@@ -11,12 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = json.load(open(os.path.join(HERE, "golden", "report_cases.json")))
 
 
+@pytest.mark.parametrize("engine", ["python", "native"])
 @pytest.mark.parametrize("idx", range(len(CASES)))
-def test_report_case(idx, tmp_path, capsys):
+def test_report_case(idx, engine, tmp_path, capsys, built):
     c = CASES[idx]
     i, o = tmp_path / "in.tsv", tmp_path / "out.tsv"
     i.write_text(c["input"])
-    rep.report(str(i), str(o), None, c["threshold"], c["disable_thresholding"])
+    rep.report(str(i), str(o), None, c["threshold"], c["disable_thresholding"], engine=engine)
     got = o.read_text()
     if isinstance(c["output"], dict):
         # the reference itself raised (KeyError when every row is filtered, __main__.py:283): we write the empty output
@@ -29,5 +30,6 @@ def test_pinned_survey_vector(tmp_path):
     """rows A,B/10 C,A/20 (cell1,UMI1), B,D/15 (cell1,UMI2), G/50 (cell3,UMI3)."""
     i, o = tmp_path / "in.tsv", tmp_path / "out.tsv"
     i.write_text("nimble_features\tnimble_score\tr1_CB\tr1_UB\nA,B\t10\tcell1\tUMI1\nC,A\t20\tcell1\tUMI1\nB,D\t15\tcell1\tUMI2\nG\t50\tcell3\tUMI3\n")
-    rep.report(str(i), str(o))
-    assert o.read_text() == "A\t1\tcell1\nB,D\t1\tcell1\nG\t1\tcell3\n"
+    for engine in ("python", "native"):
+        rep.report(str(i), str(o), engine=engine)
+        assert o.read_text() == "A\t1\tcell1\nB,D\t1\tcell1\nG\t1\tcell3\n"
