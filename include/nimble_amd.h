@@ -132,8 +132,28 @@ int32_t nb_counts_device_ptr(nb_ctx* ctx, void** d_counts, int64_t* capacity);
 typedef struct nb_fastq nb_fastq;
 int32_t nb_fastq_open(const char* path, nb_fastq** out);
 int32_t nb_fastq_close(nb_fastq* fq);
+/* worker threads used to pack a batch (the reference's -c/--num_cores, __main__.py:398); default 1 */
+int32_t nb_fastq_set_threads(nb_fastq* fq, int32_t threads);
 int32_t nb_fastq_next_batch(nb_fastq* fq, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
                             int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len, char* cbqual_out);
+
+/* ---- 10x cell-barcode whitelist correction (host): restates correct_cell_barcode,
+ * /root/reference/nimble/fastq_barcode_processor.py:73-128 (exact -> Hamming-1 candidates -> lowest quality at the
+ * differing base; per-raw-barcode cache). raw/qual/out are fixed-width cb_len per record; ok[i] = 0 drops the pair
+ * (:176-179). stats (may be NULL) receives cumulative {perfect, corrected, none}. ---- */
+typedef struct nb_whitelist nb_whitelist;
+int32_t nb_whitelist_load(const char* path, nb_whitelist** out);
+int32_t nb_whitelist_destroy(nb_whitelist* wl);
+int64_t nb_whitelist_size(const nb_whitelist* wl);
+int32_t nb_whitelist_correct(nb_whitelist* wl, const char* raw, const char* qual, int64_t n, int32_t cb_len, char* out, uint8_t* ok,
+                             int64_t* stats);
+
+/* ---- per-read TSV rows of one batch (host): replaces the Rust binary's TSV writer for barcoded input; columns
+ * nimble_features, nimble_score, r1_CB, r1_UB (consumed at /root/reference/nimble/__main__.py:237-245) + the four
+ * coverage scores (report_generation.py:275). class_feature[c] = feature string of class c or NULL if rejected. ---- */
+int32_t nb_format_tenx_rows(int64_t n, const uint32_t* cls, const uint32_t* info, const uint64_t* cov, const char* const* class_feature,
+                            int64_t n_classes, const char* cb, int32_t cb_len, const uint8_t* cb_ok, const char* umi, int32_t umi_len,
+                            char* out, int64_t out_cap, int64_t* out_len, int64_t* n_rows);
 
 /* ---- `nimble report` reducer (host, no GPU needed): per-read TSV -> feature<TAB>count<TAB>cell_barcode.
  * Replaces /root/reference/nimble/__main__.py:254-302 + nimble/utils.py:119-224 for large tables; byte-identical output

@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-from . import _lib, barcodes, engine
+from . import _lib, engine
 from .library import Library
 from .utils import append_path_string, parse_trim
 
@@ -38,9 +38,10 @@ class TenxOptions:
 
 
 class FastqReader:
-    def __init__(self, path):
+    def __init__(self, path, threads=1):
         self._h = ct.c_void_p()
         _lib.check(_lib.lib().nb_fastq_open(path.encode(), ct.byref(self._h)))
+        _lib.check(_lib.lib().nb_fastq_set_threads(self._h, int(threads)))
 
     def next_batch(self, max_reads, max_len=None, barcodes_only=False, cb_len=0, umi_len=0):
         """Returns dict(n, words, lens, cb, umi, cbq)."""
@@ -92,8 +93,8 @@ class LibraryRun:
         self.n_rows = 0
         self.fh = None
         if per_read:
-            self.fh = gzip.open(out_path, "wt") if out_path.endswith(".gz") else open(out_path, "w")
-            self.fh.write("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n")
+            self.fh = gzip.open(out_path, "wb", compresslevel=4) if out_path.endswith(".gz") else open(out_path, "wb")
+            self.fh.write(("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n").encode())
 
     def refresh_classes(self):
         """Map newly interned classes to feature strings; apply the feature-level filters of docs/SPEC.md §4."""
@@ -126,17 +127,48 @@ class LibraryRun:
         self.n_rows = len(self.bulk)
 
 
-def _write_per_read(run, cls, info, cov, cbs, umis):
+class NativeWhitelist:
+    """C++ whitelist corrector (csrc/nb_host.cpp); same rule as barcodes.BarcodeCorrector, batch at a time."""
+
+    def __init__(self, path):
+        self._h = ct.c_void_p()
+        _lib.check(_lib.lib().nb_whitelist_load(path.encode(), ct.byref(self._h)))
+        self.stats = {"cb_perfect_match": 0, "cb_corrected": 0, "cb_no_correction": 0}
+
+    def correct(self, cb, cbq):
+        """cb, cbq: [n, cb_len] 'S1' arrays -> (corrected [n, cb_len] 'S1', ok [n] uint8)."""
+        n, cb_len = cb.shape
+        cb, cbq = np.ascontiguousarray(cb), np.ascontiguousarray(cbq)
+        out, ok = np.empty_like(cb), np.zeros(n, dtype=np.uint8)
+        st = (ct.c_int64 * 3)()
+        _lib.check(_lib.lib().nb_whitelist_correct(self._h, cb.ctypes.data, cbq.ctypes.data, n, cb_len, out.ctypes.data, ok.ctypes.data, st))
+        self.stats = {"cb_perfect_match": st[0], "cb_corrected": st[1], "cb_no_correction": st[2]}
+        return out, ok
+
+    def close(self):
+        if self._h:
+            _lib.lib().nb_whitelist_destroy(self._h)
+            self._h = None
+
+
+def _write_per_read(run, cls, info_raw, cov_raw, cb, cb_ok, umi):
+    """Format this batch's rows in C++ (nb_format_tenx_rows) and append them to the run's TSV."""
     run.refresh_classes()
-    feat = run.class_feature
-    called = np.nonzero((info["reason"] == 0) & (cls != engine.NO_CLASS))[0]
-    w = run.fh.write
-    for i in called:
-        f = feat[cls[i]]
-        if f is None or cbs[i] is None:
-            continue
-        w(f"{f}\t{info['mates'][i]}\t{cbs[i]}\t{umis[i]}\t{cov[i, 0]}\t{cov[i, 1]}\t{cov[i, 2]}\t{cov[i, 3]}\n")
-        run.n_rows += 1
+    n = cls.shape[0]
+    feats = run.class_feature
+    if len(feats) != getattr(run, "_feat_n", -1):
+        run._feat_arr = (ct.c_char_p * max(1, len(feats)))(*[f.encode() if f is not None else None for f in feats])
+        run._feat_n = len(feats)
+        run._feat_max = max((len(f) for f in feats if f is not None), default=0)
+    cb, umi = np.ascontiguousarray(cb), np.ascontiguousarray(umi)
+    cap = n * (run._feat_max + cb.shape[1] + umi.shape[1] + 64) + 64
+    buf = np.empty(cap, dtype=np.uint8)
+    out_len, n_rows = ct.c_int64(), ct.c_int64()
+    _lib.check(_lib.lib().nb_format_tenx_rows(n, cls.ctypes.data, info_raw.ctypes.data, cov_raw.ctypes.data, run._feat_arr, len(feats),
+                                              cb.ctypes.data, cb.shape[1], cb_ok.ctypes.data if cb_ok is not None else None, umi.ctypes.data,
+                                              umi.shape[1], buf.ctypes.data, cap, ct.byref(out_len), ct.byref(n_rows)))
+    run.fh.write(buf[:out_len.value].tobytes())
+    run.n_rows += n_rows.value
 
 
 def align(reference, output, input, num_cores=1, strand_filter="unstranded", trim="", tmpdir=None, tenx=None, device_id=0,
@@ -169,9 +201,9 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
             runs.append(LibraryRun(lib, append_path_string(output, suffix), strand_filter, device_id, per_read))
         corrector = None
         if per_read and tenx.whitelist:
-            corrector = barcodes.BarcodeCorrector(barcodes.load_whitelist(tenx.whitelist))
-        r1 = FastqReader(input[0])
-        r2 = FastqReader(input[1]) if len(input) == 2 else None
+            corrector = NativeWhitelist(tenx.whitelist)
+        r1 = FastqReader(input[0], num_cores)
+        r2 = FastqReader(input[1], num_cores) if len(input) == 2 else None
         total, t0 = 0, time.time()
         while True:
             if per_read:
@@ -204,22 +236,16 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
             out_class = torch.empty(n, dtype=torch.int32, device=dev)
             out_info = torch.empty(n, dtype=torch.int32, device=dev)
             out_cov = torch.empty(n, dtype=torch.int64, device=dev) if per_read else None
-            cbs = umis = None
+            cbs = cb_ok = None
             if per_read:
-                raw_cb = [x.tobytes().decode() for x in b1["cb"]]
-                umis = [x.tobytes().decode() for x in b1["umi"]]
-                if corrector:
-                    cbq = [x.tobytes().decode() for x in b1["cbq"]]
-                    cbs = [corrector.correct(c, q) for c, q in zip(raw_cb, cbq)]
-                else:
-                    cbs = raw_cb
+                cbs, cb_ok = corrector.correct(b1["cb"], b1["cbq"]) if corrector else (b1["cb"], None)
             for run in runs:
                 run.ctx.align_batch(run.cfg, d_reads, d_lens, max_len, out_class, out_info, out_cov, mates=d_mates, mate_lens=d_mlens,
                                     mate_max_len=mmax, n=n)
                 run.ctx.sync()
                 if per_read:
-                    _write_per_read(run, out_class.cpu().numpy().view(np.uint32), engine.decode_info(out_info.cpu().numpy().view(np.uint32)),
-                                    engine.decode_cov(out_cov.cpu().numpy().view(np.uint64)), cbs, umis)
+                    _write_per_read(run, out_class.cpu().numpy().view(np.uint32), out_info.cpu().numpy().view(np.uint32),
+                                    out_cov.cpu().numpy().view(np.uint64), cbs, cb_ok, b1["umi"])
             total += n
         for run in runs:
             run.finish()

@@ -133,3 +133,27 @@ def test_align_without_gpu_returns_nonzero(built, tmp_path, capsys):
     assert align(str(tmp_path / "l.json"), str(tmp_path / "o.tsv"), [str(fq)], 1, "unstranded", "", None) == 1
     assert "no CPU alignment path" in capsys.readouterr().err
     assert align(str(tmp_path / "l.json"), str(tmp_path / "o.tsv"), ["x.bam"], 1, "unstranded", "", None) == 1
+
+
+def test_native_whitelist_matches_python_rule(built, tmp_path):
+    """C++ corrector (nb_whitelist_correct) == barcodes.BarcodeCorrector on random barcodes incl. cache order effects."""
+    from nimble_amd.align import NativeWhitelist
+    rng = np.random.default_rng(11)
+    wl = sorted({"".join("ACGT"[c] for c in rng.integers(0, 4, 8)) for _ in range(3000)})
+    p = tmp_path / "wl.txt.gz"
+    with gzip.open(p, "wt") as f:
+        f.write("\n".join(wl) + "\n\n")
+    raws, quals = [], []
+    for _ in range(6000):
+        c = list(wl[rng.integers(0, len(wl))])
+        for _ in range(int(rng.integers(0, 3))):
+            c[rng.integers(0, 8)] = "ACGTN"[rng.integers(0, 5)]
+        raws.append("".join(c)); quals.append("".join(chr(33 + int(q)) for q in rng.integers(2, 41, 8)))
+    raws += raws[:500]; quals += ["".join(chr(33 + int(q)) for q in rng.integers(2, 41, 8)) for _ in range(500)]   # repeats: cache decides
+    py = barcodes.BarcodeCorrector(barcodes.load_whitelist(str(p)))
+    want = [py.correct(r, q) for r, q in zip(raws, quals)]
+    nat = NativeWhitelist(str(p))
+    cb = np.array([list(r) for r in raws], dtype="S1"); cq = np.array([list(q) for q in quals], dtype="S1")
+    out, ok = nat.correct(cb, cq)
+    got = [o.tobytes().decode() if k else None for o, k in zip(out, ok)]
+    assert got == want and nat.stats == py.stats and 0 < sum(w is None for w in want) < len(want)
