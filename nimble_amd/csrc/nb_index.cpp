@@ -151,28 +151,40 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     }
   }
 
-  // 5. canonical table, linear probing, load factor <= 0.5
-  int cap_log2 = 10;
-  while ((1ull << cap_log2) < 2 * recs.size()) ++cap_log2;
-  ix->cap_log2 = cap_log2;
-  ix->slots.assign((size_t)1 << cap_log2, Slot{SLOT_EMPTY, {PAY_ABSENT, PAY_ABSENT}});
-  const uint64_t smask = ((uint64_t)1 << cap_log2) - 1;
-  int64_t n_canon = 0;
-  for (const auto& r : recs) {
-    const uint64_t y = rc_kmer_host(r.kmer, k);
-    const uint64_t canon = std::min(r.kmer, y);
-    const int o = (r.kmer != canon) ? 1 : 0;
-    const uint32_t pay = make_payload(r.colour, r.lext, r.rext, r.r_int, r.l_int);
-    uint64_t h = slot_of(canon, cap_log2);
+  // 5. canonical table: 32-byte buckets of two slots, load <= TABLE_MAX_LOAD (nb_internal.h).
+  struct Canon { uint64_t key; uint32_t pay[2]; };
+  std::vector<Canon> canons; canons.reserve(recs.size());
+  {
+    std::vector<std::pair<uint64_t, std::pair<int, uint32_t>>> tmp; tmp.reserve(recs.size());
+    for (const auto& r : recs) {
+      const uint64_t y = rc_kmer_host(r.kmer, k), canon = std::min(r.kmer, y);
+      const uint32_t pay = make_payload(r.colour, r.lext, r.rext, r.r_int, r.l_int);
+      tmp.push_back({canon, {(r.kmer != canon) ? 1 : 0, pay}});
+      if (r.kmer == y) tmp.push_back({canon, {1, pay}});   // palindrome: both orientations are this k-mer
+    }
+    std::sort(tmp.begin(), tmp.end());
+    for (size_t i = 0; i < tmp.size();) {
+      Canon c{tmp[i].first, {PAY_ABSENT, PAY_ABSENT}};
+      size_t j = i;
+      while (j < tmp.size() && tmp[j].first == c.key) { c.pay[tmp[j].second.first] = tmp[j].second.second; ++j; }
+      canons.push_back(c); i = j;
+    }
+  }
+  const int64_t n_canon = (int64_t)canons.size();
+  uint64_t nb64 = (uint64_t)((double)n_canon / (SLOTS_PER_BUCKET * TABLE_MAX_LOAD)) + 1;
+  if (nb64 < 256) nb64 = 256;
+  if (nb64 > 0x7FFFFFFFull) { delete ix; set_error("nb_index_build: k-mer table would exceed 2^31 buckets"); return NB_ERR_UNSUPPORTED; }
+  ix->hash.mf = 0x9E3779B1u; ix->hash.m1 = 0x85EBCA77u; ix->hash.n_buckets = (uint32_t)nb64;
+  Bucket empty; for (int j = 0; j < SLOTS_PER_BUCKET; ++j) { empty.slot[j].key = KEY_EMPTY; empty.slot[j].pay[0] = empty.slot[j].pay[1] = PAY_ABSENT; }
+  ix->buckets.assign((size_t)nb64, empty);
+  for (const Canon& c : canons) {
+    uint32_t b = kmer_bucket(c.key, ix->hash);
     for (;;) {
-      Slot& s = ix->slots[h];
-      if (s.key == SLOT_EMPTY) { s.key = canon; ++n_canon; }
-      if (s.key == canon) {
-        s.pay[o] = pay;
-        if (r.kmer == y) s.pay[1] = pay;  // palindrome: both orientations are this k-mer
-        break;
-      }
-      h = (h + 1) & smask;
+      Bucket& bk = ix->buckets[b];
+      int j = 0; while (j < SLOTS_PER_BUCKET && (bk.slot[j].key & KEY_MASK) != KEY_EMPTY) ++j;
+      if (j < SLOTS_PER_BUCKET) { bk.slot[j].key = (bk.slot[j].key & KEY_OVERFLOW) | c.key; bk.slot[j].pay[0] = c.pay[0]; bk.slot[j].pay[1] = c.pay[1]; break; }
+      bk.slot[0].key |= KEY_OVERFLOW;                         // full: lookups of keys homed at or before b continue
+      b = (b + 1 == ix->hash.n_buckets) ? 0 : b + 1;
     }
   }
   ix->n_canonical = n_canon;

@@ -11,21 +11,49 @@ namespace nb {
 // ---- k-mer encoding (product side): base j of the k-mer sits at bits [2j, 2j+2): FIRST base LEAST significant,
 // so that a k-mer is a plain bit-field of the packed read (nimble_amd.h, nb_pack_reads). ----
 
-// One slot of the canonical-k-mer table, 16 B, read with one dwordx4 load.
-//   key    canonical k-mer = min(x, rc(x)); NB_SLOT_EMPTY when free
-//   pay[0] payload of the k-mer equal to `key` as it occurs in the reference (stranded), or NB_PAY_ABSENT
-//   pay[1] payload of rc(key) as it occurs in the reference, or NB_PAY_ABSENT (palindromes: pay[1] == pay[0])
+// The canonical-k-mer table is an array of 32-byte BUCKETS of two 16-byte slots {key, pay[2]}; a lookup reads its home
+// bucket with two dwordx4 loads issued together (one L2 request: both halves share a 64-byte line) and finds key AND
+// payload there — no probe loop and no dependent second load. The builder keeps the load at <= 0.10 (0.2 keys per
+// bucket on average), so a key overflows its home bucket with probability ~1e-3; when one does it goes to the next
+// bucket and every bucket on the way gets the OVERFLOW flag, which sends the (rare) lookup one bucket further.
+// Why not denser: one read per wave means 131 lookups in lock-step, so any per-lookup retry probability above ~1e-3
+// makes nearly every wave pay a second (and third) iteration — per-slot linear probing at load 0.3 cost ~340 VALU
+// instructions per read in its probe loop. Why not two-choice cuckoo: it doubles the L2-miss requests and hits the
+// fabric request rate (measured 36 ms vs 22.5 ms per 10M reads). Why not 64-byte/4-key buckets with split key/payload
+// halves: the payload becomes a dependent second load and the 4 key words cost registers (107 VGPRs, 24.8 ms).
+//   key word  bits [0,62) canonical k-mer = min(x, rc(x)); bit 62 set = empty slot; bit 63 (slot 0 only) = overflow flag
+//   pay[0]    payload of the k-mer equal to the key as it occurs in the reference (stranded), or PAY_ABSENT
+//   pay[1]    payload of rc(key) as it occurs in the reference, or PAY_ABSENT (palindromes: both set)
 // payload bits: [0,4) rext mask  [4,8) lext mask  8 r_internal  9 l_internal  [10,32) colour id
 struct Slot {
   uint64_t key;
   uint32_t pay[2];
 };
-static_assert(sizeof(Slot) == 16, "slot must be 16 bytes");
+struct Bucket { Slot slot[2]; };
+static_assert(sizeof(Bucket) == 32, "bucket must be 32 bytes");
+constexpr int SLOTS_PER_BUCKET = 2;
+constexpr double TABLE_MAX_LOAD = 0.10;
 
-constexpr uint64_t SLOT_EMPTY = ~0ull;
+constexpr uint64_t KEY_EMPTY = 1ull << 62;
+constexpr uint64_t KEY_OVERFLOW = 1ull << 63;
+constexpr uint64_t KEY_MASK = ~KEY_OVERFLOW;
 constexpr uint32_t PAY_ABSENT = 0xFFFFFFFFu;
 constexpr uint32_t MAX_COLOURS = (1u << 22) - 1;  // colour ids are 22 bits; all-ones reserved by PAY_ABSENT
-constexpr uint64_t HASH_MULT = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t HASH_MULT = 0x9E3779B97F4A7C15ull;   // class-table hash (content hash -> slot)
+
+// bucket of a canonical k-mer: fold to 32 bits, one multiplicative mix, multiply-high range reduction
+// (3 x v_mul_lo_u32 + 1 x v_mul_hi_u32 on the GPU); n_buckets need not be a power of two.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define NB_HD __host__ __device__
+#else
+#define NB_HD
+#endif
+struct KmerHash { uint32_t mf, m1, n_buckets; };
+NB_HD inline uint32_t kmer_bucket(uint64_t canon, const KmerHash& h) {
+  uint32_t m = ((uint32_t)canon ^ ((uint32_t)(canon >> 32) * h.mf)) * h.m1;
+  m ^= m >> 15;
+  return (uint32_t)(((uint64_t)(m * 0x2C1B3C6Du) * (uint64_t)h.n_buckets) >> 32);
+}
 
 inline uint32_t make_payload(uint32_t colour, uint32_t lext, uint32_t rext, uint32_t r_int, uint32_t l_int) {
   return (colour << 10) | (l_int << 9) | (r_int << 8) | (lext << 4) | rext;
@@ -39,16 +67,15 @@ inline uint64_t rc_kmer_host(uint64_t x, int k) {
   return r;
 }
 
-inline uint64_t slot_of(uint64_t canon, int cap_log2) { return (canon * HASH_MULT) >> (64 - cap_log2); }
 
 struct HostIndex {
   int k = 20;
   int n_seqs = 0;
   int words = 0;                      // u64 words per colour row
-  int cap_log2 = 0;
+  KmerHash hash{};                    // hash.n_buckets buckets of SLOTS_PER_BUCKET slots
   int64_t n_kmers = 0;                // distinct stranded k-mers
   int64_t n_canonical = 0;
-  std::vector<Slot> slots;            // 1 << cap_log2
+  std::vector<Bucket> buckets;        // hash.n_buckets
   std::vector<uint64_t> eq_rows;      // n_colours * words; colour ids ascend by set size
   std::vector<uint32_t> eq_sizes;     // n_colours
   // device copies (owned by the ctx that uploaded; recorded here for stats)

@@ -26,12 +26,24 @@ namespace nb {
 // ------------------------------------------------------------------------------------------------------------
 // device-side views
 struct DevIndex {
-  const Slot* slots;
-  const uint64_t* eq;   // n_colours * W
-  int cap_log2;
-  int W;                // u64 words per colour row
+  const Bucket* buckets;  // hash.n_buckets 64-byte buckets (nb_internal.h)
+  const uint64_t* eq;     // n_colours * W
+  KmerHash hash;
+  int W;                  // u64 words per colour row
   int K;
 };
+
+// One bucket probe for one lane. Returns true on a hit and fills p0/p1; `more` = the bucket is flagged OVERFLOW (the key
+// may live in the next bucket).
+__device__ __forceinline__ bool probe_bucket(const Bucket* __restrict__ B, uint32_t b, uint64_t canon, uint32_t& p0, uint32_t& p1, bool& more) {
+  const uint4* kp = reinterpret_cast<const uint4*>(&B[b]);
+  const uint4 a = kp[0], c = kp[1];
+  const uint64_t k0 = ((uint64_t)a.y << 32) | a.x, k1 = ((uint64_t)c.y << 32) | c.x;
+  const bool m0 = (k0 & KEY_MASK) == canon, m1 = k1 == canon;
+  more = (k0 >> 63) != 0;
+  p0 = m0 ? a.z : c.z; p1 = m0 ? a.w : c.w;
+  return m0 || m1;
+}
 
 struct DevClasses {
   unsigned long long* keys;    // cap slots, 0 = free
@@ -313,14 +325,14 @@ __device__ __forceinline__ PosFacts position_facts(const DevIndex& ix, const uin
   const uint64_t y = rc_kmer(x, K);
   const uint64_t canon = x < y ? x : y;
   const int o = (x != canon) ? 1 : 0;
-  const uint64_t smask = (1ull << ix.cap_log2) - 1;
-  uint64_t h = (canon * HASH_MULT) >> (64 - ix.cap_log2);
-  for (;;) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(&ix.slots[h]);
-    const uint64_t key = ((uint64_t)raw.y << 32) | raw.x;
-    if (key == canon) { f.payF = o ? raw.w : raw.z; f.payR = o ? raw.z : raw.w; break; }
-    if (key == SLOT_EMPTY) break;
-    h = (h + 1) & smask;
+  {
+    uint32_t b = kmer_bucket(canon, ix.hash), p0 = PAY_ABSENT, p1 = PAY_ABSENT;
+    for (;;) {
+      bool more;
+      if (probe_bucket(ix.buckets, b, canon, p0, p1, more)) { f.payF = o ? p1 : p0; f.payR = o ? p0 : p1; break; }
+      if (!more) break;
+      b = (b + 1 == ix.hash.n_buckets) ? 0u : b + 1;
+    }
   }
   if (f.payF != PAY_ABSENT) {
     f.hF = true;
@@ -389,8 +401,7 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
   const bool hiHalf = lane >= 32;
   const int sh = (lane & 31) * 2;
   const uint64_t kmask = (1ull << (2 * K)) - 1, nkmask = (1ull << K) - 1;
-  const uint64_t smask = (1ull << ix.cap_log2) - 1;
-  uint64_t canon[NR]; uint64_t hh[NR]; uint32_t meta[NR];
+  uint64_t canon[NR]; uint32_t bk[NR]; uint32_t meta[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int i = lane + 64 * r;
@@ -411,34 +422,39 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
     const uint64_t y = rc_kmer(x, K);
     const uint64_t c = x < y ? x : y;
     canon[r] = c;
-    hh[r] = (c * HASH_MULT) >> (64 - ix.cap_log2);
+    bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;   // idle lanes read bucket 0: every load is unconditional, so the
+                                                      // key halves of all NR buckets of a read are in flight together
     meta[r] = (validk ? 1u : 0u) | ((x != c) ? 2u : 0u) | (next_ok ? 4u : 0u) | (nextb << 3) | (prev_ok ? 32u : 0u) | (prevb << 6);
   }
-  uint32_t payF[NR], payR[NR]; bool pend[NR];
+  // bucket lookup (nb_internal.h): both 16-byte slots of the home bucket, key and payload together
+  const Bucket* __restrict__ B = ix.buckets;
+  uint4 ka[NR], kb[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) { payF[r] = PAY_ABSENT; payR[r] = PAY_ABSENT; pend[r] = meta[r] & 1u; }
-  for (;;) {
-    // unconditional loads (idle lanes read slot 0) so that all NR probes are in flight together: no exec-masked branch
-    uint4 raw[NR];
+  for (int r = 0; r < NR; ++r) { const uint4* kp = reinterpret_cast<const uint4*>(&B[bk[r]]); ka[r] = kp[0]; kb[r] = kp[1]; }
+  uint32_t payF[NR], payR[NR]; bool ovf[NR]; bool any_ovf = false;
 #pragma unroll
-#if defined(NB_ABLATE) && NB_ABLATE == 3
-    for (int r = 0; r < NR; ++r) { raw[r].x = (uint32_t)canon[r]; raw[r].y = (uint32_t)(canon[r] >> 32); raw[r].z = (uint32_t)hh[r] << 10 | 0xFF; raw[r].w = PAY_ABSENT; }  // timing-only: no table loads, every k-mer "hits"
-#else
-    for (int r = 0; r < NR; ++r) raw[r] = *reinterpret_cast<const uint4*>(&ix.slots[pend[r] ? hh[r] : 0ull]);
-#endif
-    bool more = false;
+  for (int r = 0; r < NR; ++r) {
+    const uint64_t k0 = ((uint64_t)ka[r].y << 32) | ka[r].x, k1 = ((uint64_t)kb[r].y << 32) | kb[r].x;
+    const bool valid = meta[r] & 1u, o = meta[r] & 2u;
+    const bool m0 = (k0 & KEY_MASK) == canon[r], m1 = k1 == canon[r];
+    const bool found = valid && (m0 || m1);
+    ovf[r] = valid && !found && (k0 >> 63);
+    any_ovf |= ovf[r];
+    const uint32_t p0 = m0 ? ka[r].z : kb[r].z, p1 = m0 ? ka[r].w : kb[r].w;
+    payF[r] = found ? (o ? p1 : p0) : PAY_ABSENT;
+    payR[r] = found ? (o ? p0 : p1) : PAY_ABSENT;
+  }
+  if (__ballot(any_ovf)) {   // rare (load <= 0.10): some key overflowed its home bucket, follow the chain
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const uint64_t key = ((uint64_t)raw[r].y << 32) | raw[r].x;
-      const bool hit = pend[r] && key == canon[r], stop = key == SLOT_EMPTY;
-      const bool o = meta[r] & 2u;
-      payF[r] = hit ? (o ? raw[r].w : raw[r].z) : payF[r];
-      payR[r] = hit ? (o ? raw[r].z : raw[r].w) : payR[r];
-      pend[r] = pend[r] && !hit && !stop;
-      hh[r] = (hh[r] + 1) & smask;
-      more |= pend[r];
+      uint32_t b = bk[r]; bool pending = ovf[r];
+      while (pending) {
+        b = (b + 1 == ix.hash.n_buckets) ? 0u : b + 1;
+        uint32_t p0, p1; bool more;
+        if (probe_bucket(B, b, canon[r], p0, p1, more)) { const bool o = meta[r] & 2u; payF[r] = o ? p1 : p0; payR[r] = o ? p0 : p1; pending = false; }
+        else pending = more;
+      }
     }
-    if (__ballot(more) == 0) break;
   }
   Mask<NR> HF, RF, LF, HR, RR, LR;
 #pragma unroll
@@ -880,7 +896,7 @@ struct nb_ctx {
   int device = 0;
   int n_cu = 256;
   // bound index (device copies)
-  nb::Slot* d_slots = nullptr; uint64_t* d_eq = nullptr; int cap_log2 = 0, W = 0, K = 0, n_seqs = 0; int64_t index_bytes = 0;
+  nb::Bucket* d_slots = nullptr; uint64_t* d_eq = nullptr; nb::KmerHash hash{}; int W = 0, K = 0, n_seqs = 0; int64_t index_bytes = 0;
   // class table
   nb::DevClasses ct{}; int64_t max_classes = 0;
   // score_percent table
@@ -903,13 +919,25 @@ static int ensure_pct_table(nb_ctx* c, double score_percent, int max_len, hipStr
   c->pct_len = max_len + 1; c->pct_value = score_percent; return NB_OK;
 }
 
+// Persistent-style grid: as many 256-thread blocks as are co-resident (occupancy query x CUs), every wave strides over
+// the batch. Sizing the grid above residency would run the surplus blocks as a second, partly empty round.
+template <class K>
+static int resident_blocks(nb_ctx* c, K kernel, long long n_templates) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  if (per_cu > 8) per_cu = 8;
+  long long blocks = (long long)c->n_cu * per_cu;
+  const long long need = (n_templates + 3) / 4;
+  if (blocks > need) blocks = need;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
 template <int NR, int TW>
 static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
-  const long long waves_needed = a.n;
-  long long blocks = (waves_needed + 3) / 4;
-  const long long cap = (long long)c->n_cu * 8;   // 8 blocks of 4 waves per CU = 32 waves/CU
-  if (blocks > cap) blocks = cap;
-  if (blocks < 1) blocks = 1;
+  static thread_local int cached_blocks = 0; static thread_local int cached_cu = 0;
+  if (!cached_blocks || cached_cu != c->n_cu) { cached_blocks = resident_blocks(c, nb_align_se_kernel<NR, TW>, 1ll << 40); cached_cu = c->n_cu; }
+  long long blocks = cached_blocks; const long long need = (a.n + 3) / 4;
+  if (blocks > need) blocks = need;
   hipLaunchKernelGGL((nb_align_se_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a, a.reads);
   NB_HIP(hipGetLastError());
   return NB_OK;
@@ -917,10 +945,7 @@ static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStrea
 
 template <int NR, int TW>
 static int launch_general(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
-  long long blocks = (a.n + 3) / 4;
-  const long long cap = (long long)c->n_cu * 8;
-  if (blocks > cap) blocks = cap;
-  if (blocks < 1) blocks = 1;
+  const long long blocks = resident_blocks(c, nb_align_general_kernel<NR, TW>, a.n);
   hipLaunchKernelGGL((nb_align_general_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
   NB_HIP(hipGetLastError());
   return NB_OK;
@@ -1000,9 +1025,9 @@ int32_t nb_index_destroy(nb_index* ix) { if (ix) { delete ix->h; delete ix; } re
 int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
   if (!ix || !s) { set_error("nb_index_stats: null argument"); return NB_ERR_INVALID; }
   const HostIndex& h = *ix->h;
-  s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = (int64_t)h.slots.size();
+  s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
   s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
-  s->device_bytes = (int64_t)(h.slots.size() * sizeof(Slot) + h.eq_rows.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
+  s->device_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.eq_rows.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
   return NB_OK;
 }
 
@@ -1014,17 +1039,17 @@ int32_t nb_index_query(const nb_index* ix, const char* kmer, uint8_t* lext, uint
     x |= (uint64_t)c << (2 * j);
   }
   const uint64_t y = rc_kmer_host(x, h.k), canon = x < y ? x : y; const int o = (x != canon);
-  const uint64_t smask = h.slots.size() - 1; uint64_t s = slot_of(canon, h.cap_log2);
+  uint32_t b = kmer_bucket(canon, h.hash);
   for (;;) {
-    const Slot& sl = h.slots[s];
-    if (sl.key == SLOT_EMPTY) return 0;
-    if (sl.key == canon) {
-      const uint32_t p = sl.pay[o]; if (p == PAY_ABSENT) return 0;
-      if (rext) *rext = p & 15; if (lext) *lext = (p >> 4) & 15; if (r_int) *r_int = (p >> 8) & 1; if (l_int) *l_int = (p >> 9) & 1;
-      if (bits) std::memcpy(bits, h.eq_rows.data() + (size_t)(p >> 10) * h.words, (size_t)h.words * 8);
-      return 1;
-    }
-    s = (s + 1) & smask;
+    const Bucket& bk = h.buckets[b];
+    for (int j = 0; j < SLOTS_PER_BUCKET; ++j) if ((bk.slot[j].key & KEY_MASK) == canon) {
+        const uint32_t p = bk.slot[j].pay[o]; if (p == PAY_ABSENT) return 0;
+        if (rext) *rext = p & 15; if (lext) *lext = (p >> 4) & 15; if (r_int) *r_int = (p >> 8) & 1; if (l_int) *l_int = (p >> 9) & 1;
+        if (bits) std::memcpy(bits, h.eq_rows.data() + (size_t)(p >> 10) * h.words, (size_t)h.words * 8);
+        return 1;
+      }
+    if (!(bk.slot[0].key & KEY_OVERFLOW)) return 0;
+    b = (b + 1 == h.hash.n_buckets) ? 0u : b + 1;
   }
 }
 
@@ -1033,13 +1058,13 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   NB_HIP(hipSetDevice(c->device));
   HostIndex& h = *ix->h;
   (void)hipFree(c->d_slots); (void)hipFree(c->d_eq); (void)hipFree(c->ct.rows); c->d_slots = nullptr; c->d_eq = nullptr; c->ct.rows = nullptr;
-  NB_HIP(hipMalloc((void**)&c->d_slots, h.slots.size() * sizeof(Slot)));
+  NB_HIP(hipMalloc((void**)&c->d_slots, h.buckets.size() * sizeof(Bucket)));
   NB_HIP(hipMalloc((void**)&c->d_eq, h.eq_rows.size() * 8));
-  NB_HIP(hipMemcpy(c->d_slots, h.slots.data(), h.slots.size() * sizeof(Slot), hipMemcpyHostToDevice));
+  NB_HIP(hipMemcpy(c->d_slots, h.buckets.data(), h.buckets.size() * sizeof(Bucket), hipMemcpyHostToDevice));
   NB_HIP(hipMemcpy(c->d_eq, h.eq_rows.data(), h.eq_rows.size() * 8, hipMemcpyHostToDevice));
   NB_HIP(hipMalloc((void**)&c->ct.rows, (size_t)c->max_classes * (size_t)h.words * 8));
-  c->cap_log2 = h.cap_log2; c->W = h.words; c->K = h.k; c->n_seqs = h.n_seqs;
-  c->index_bytes = (int64_t)(h.slots.size() * sizeof(Slot) + h.eq_rows.size() * 8); h.uploaded = 1;
+  c->hash = h.hash; c->W = h.words; c->K = h.k; c->n_seqs = h.n_seqs;
+  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.eq_rows.size() * 8); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
 }
 
@@ -1082,7 +1107,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   NB_HIP(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
   int rc = ensure_pct_table(c, cfg->score_percent, lmax, s); if (rc != NB_OK) return rc;
-  DevIndex ix{c->d_slots, c->d_eq, c->cap_log2, c->W, c->K};
+  DevIndex ix{c->d_slots, c->d_eq, c->hash, c->W, c->K};
   BatchArgs a{};
   a.reads = d_reads; a.lens = d_lens; a.max_len = max_len; a.stride = (int)nb_packed_stride_words(max_len); a.nwb = (max_len + 31) / 32;
   a.mates = d_mates; a.mate_lens = d_mate_lens; a.mate_max_len = mate_max_len;
