@@ -3,11 +3,13 @@
 // Replaces the per-read work of the Rust `nimble-aligner` binary spawned at /root/reference/nimble/__main__.py:195
 // (k-mer extraction, index lookup, equivalence-class intersection, scoring, filtering, counting). Semantics:
 // docs/SPEC.md. Formulation: ONE READ PER WAVE, ONE K-MER POSITION PER LANE.
-//   1. every lane extracts its k-mer from the 2-bit packed read, canonicalises it and probes the canonical-k-mer
-//      table once; the slot carries the payload of BOTH strands, so one probe serves read and reverse complement;
+//   1. every lane extracts its k-mer from the 2-bit packed read, canonicalises it and reads its 32-byte home bucket of
+//      the canonical-k-mer table; the slot carries the payload of BOTH strands, so one lookup serves read and reverse
+//      complement;
 //   2. wave ballots turn per-position facts into bit masks (hit, right-extendable, left-extendable);
 //   3. the SPEC §3 walk (stride-3 seeding, left extension, runs, re-seeding) becomes a handful of find-first-bit
-//      operations on those masks, executed uniformly by the wave;
+//      operations on those masks, executed uniformly by the wave (the reverse strand is walked downwards over the same
+//      read-position order, no mask reversal);
 //   4. the colours of the visited positions are intersected: the smallest class row seeds an accumulator spread
 //      over the lanes (one u64 word per lane), then for each non-zero word every visited lane gathers its own
 //      class's word and a wave AND-reduction folds them;
@@ -89,23 +91,19 @@ template <class OP> __device__ __forceinline__ uint32_t row_reduce(uint32_t v) {
   t = dpp_mov<0x128>(v); v = OP::f(v, t);
   return v;
 }
-#define NB_ROW_REDUCE(v, OP) v = row_reduce<OP>(v)
-#define NB_OP_MIN OpMin
-#define NB_OP_AND OpAnd
-#define NB_OP_ADD OpAdd
 __device__ __forceinline__ uint32_t rows4(uint32_t v, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 16 * k); }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  NB_ROW_REDUCE(v, NB_OP_MIN);
+  v = row_reduce<OpMin>(v);
   const uint32_t a = rows4(v, 0), b = rows4(v, 1), c = rows4(v, 2), d = rows4(v, 3);
   const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
   return ab < cd ? ab : cd;
 }
 __device__ __forceinline__ uint32_t wave_and_u32(uint32_t v) {
-  NB_ROW_REDUCE(v, NB_OP_AND);
+  v = row_reduce<OpAnd>(v);
   return rows4(v, 0) & rows4(v, 1) & rows4(v, 2) & rows4(v, 3);
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-  NB_ROW_REDUCE(v, NB_OP_ADD);
+  v = row_reduce<OpAdd>(v);
   return rows4(v, 0) + rows4(v, 1) + rows4(v, 2) + rows4(v, 3);
 }
 __device__ __forceinline__ uint64_t wave_and_u64(uint64_t v) {
@@ -189,26 +187,6 @@ template <int NR> __device__ __forceinline__ void set_range(Mask<NR>& m, int lo,
       m.w[wi] |= hi_mask & (~0ull << a);
     }
   }
-}
-// out bit j = in bit (P-1-j), j in [0,P)
-template <int NR> __device__ __forceinline__ Mask<NR> reverse_mask(const Mask<NR>& in, int P) {
-  uint64_t t[NR + 1];
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) t[wi] = __brevll(in.w[NR - 1 - wi]);   // full reversal over NR*64 bits
-  t[NR] = 0;
-  const int S = NR * 64 - P, ws = S >> 6, bs = S & 63;                    // then shift right by S
-  Mask<NR> out;
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) {
-    uint64_t lo = 0, hi = 0;
-#pragma unroll
-    for (int s = 0; s <= NR; ++s) {
-      if (s == wi + ws) lo = t[s];
-      if (s == wi + ws + 1) hi = t[s];
-    }
-    out.w[wi] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
-  }
-  return out;
 }
 template <int NR> __device__ __forceinline__ bool any_set(const Mask<NR>& m) {
   uint64_t v = 0;
@@ -354,38 +332,10 @@ template <int NR> struct Strand {
   uint32_t col[NR];    // this lane's colour at position lane + 64 r on this strand
 };
 
-// Steps 1-3 for one sequence: facts for every position, ballots, both walks.
-template <int NR>
-__device__ __forceinline__ void map_both_strands(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int lane,
-                                                 Strand<NR>& F, Strand<NR>& R) {
-  const int K = ix.K, P = L - K + 1;
-  Mask<NR> HF, RF, LF, HR, RR, LR;
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int i = lane + 64 * r;
-    const PosFacts f = position_facts(ix, rp, nwb, L, i, i < P);
-    F.col[r] = f.payF >> 10; R.col[r] = f.payR >> 10;
-    HF.w[r] = __ballot(f.hF); RF.w[r] = __ballot(f.rF); LF.w[r] = __ballot(f.lF);
-    HR.w[r] = __ballot(f.hR); RR.w[r] = __ballot(f.rR); LR.w[r] = __ballot(f.lR);
-  }
-  F.cov = any_set<NR>(HF) ? walk_masks<NR>(HF, RF, LF, L, K, F.V) : 0;
-  if (any_set<NR>(HR)) {
-    // rc strand position j is read position P-1-j: reverse the masks into walk order, walk, reverse the result back
-    const Mask<NR> h = reverse_mask<NR>(HR, P), r = reverse_mask<NR>(RR, P), l = reverse_mask<NR>(LR, P);
-    Mask<NR> v;
-    R.cov = walk_masks<NR>(h, r, l, L, K, v);
-    R.V = reverse_mask<NR>(v, P);
-  } else {
-    R.cov = 0;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) R.V.w[r] = 0;
-  }
-}
-
-// Fast-path twin of map_both_strands for the hot kernel: the whole packed record is fetched with wave-uniform loads
-// first (one round trip), every round's k-mer is prepared, then the table probes of ALL rounds are issued together
-// and collisions are resolved in lock-step, so a read costs ~1-2 dependent memory round trips here instead of 3+ per
-// round. Same results as map_both_strands (tests compare both kernels against the oracle).
+// Steps 1-3 of the hot kernel for one read: the whole packed record is fetched with wave-uniform (scalar) loads first,
+// every round's k-mer is prepared, then the bucket loads of ALL rounds are issued together (one dependent memory round
+// trip for the lookups of a read), ballots build the masks and both strands are walked. The general kernel reaches the
+// same facts through position_facts(); tests hold both kernels to the oracle.
 template <int NR>
 __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int lane,
                                                       Strand<NR>& F, Strand<NR>& R) {
