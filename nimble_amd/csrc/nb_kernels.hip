@@ -65,6 +65,7 @@ struct BatchArgs {
   long long n;
   uint32_t* out_class; uint32_t* out_info; uint64_t* out_cov;
   const uint16_t* pct_min;   // pct_min[L] = smallest cov with (double)cov/(double)L >= score_percent, L in 0..max(max_len,mate_max_len)
+  int pct_fixed;             // pct_min[max_len], used when every read has length max_len (lens == NULL): no table load
   int score_threshold, score_filter, num_mismatches, discard_multiple, intersect_level, require_valid_pair, strand_filter;
 };
 
@@ -430,6 +431,218 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// "Three positions per lane" front end for reads with 129..192 k-mer positions (150-bp reads at k = 20 have 131):
+// lane l owns positions 3l, 3l+1, 3l+2. One window extraction and ONE reverse complement serve the three k-mers, and —
+// the point — every mask is a single 64-bit word per residue class (bit l of m[r] <-> position 3l + r) instead of a
+// three-word bit string: the SPEC §3 walk needs no multiword arithmetic, and the stride-3 seed scan of SPEC §3 is a
+// plain find-first-bit on one word because a residue class IS a word. Downstream code is untouched: Strand<3>.V.w[r] /
+// col[r] simply mean "residue r" instead of "round r".
+struct Tri { uint64_t m[3]; };
+
+__device__ __forceinline__ bool tri_bit(const Tri& t, int l, int r) {
+  const uint64_t w = r == 0 ? t.m[0] : (r == 1 ? t.m[1] : t.m[2]);
+  return (w >> l) & 1;
+}
+// first position >= from with residue from % 3 whose bit is set, or -1
+__device__ __forceinline__ int tri_ffs_stride3(const Tri& H, int from) {
+  const int l0 = from / 3, r = from - 3 * l0;
+  const uint64_t w = r == 0 ? H.m[0] : (r == 1 ? H.m[1] : H.m[2]);
+  const uint64_t m = w >> l0;
+  return m ? 3 * (l0 + __builtin_ctzll(m)) + r : -1;
+}
+// last position <= from with residue from % 3 whose bit is set, or -1
+__device__ __forceinline__ int tri_fls_stride3_down(const Tri& H, int from) {
+  const int l0 = from / 3, r = from - 3 * l0;
+  const uint64_t w = r == 0 ? H.m[0] : (r == 1 ? H.m[1] : H.m[2]);
+  const uint64_t m = l0 >= 63 ? w : (w & ((2ull << l0) - 1));
+  return m ? 3 * (63 - __builtin_clzll(m)) + r : -1;
+}
+// first position >= p whose bit is ZERO (a zero is guaranteed at or before position 191)
+__device__ __forceinline__ int tri_ffz_from(const Tri& X, int p) {
+  const int l = p / 3, r = p - 3 * l;
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) if (rr >= r && !((X.m[rr] >> l) & 1)) return 3 * l + rr;
+  if (l >= 63) return 192;
+  const uint64_t m = ~(X.m[0] & X.m[1] & X.m[2]) >> (l + 1);
+  if (!m) return 192;
+  const int zl = l + 1 + __builtin_ctzll(m);
+  const int rr = !((X.m[0] >> zl) & 1) ? 0 : (!((X.m[1] >> zl) & 1) ? 1 : 2);
+  return 3 * zl + rr;
+}
+// last position <= p whose bit is ZERO (position 0 is guaranteed zero in the masks passed here)
+__device__ __forceinline__ int tri_flz_upto(const Tri& X, int p) {
+  const int l = p / 3, r = p - 3 * l;
+#pragma unroll
+  for (int rr = 2; rr >= 0; --rr) if (rr <= r && !((X.m[rr] >> l) & 1)) return 3 * l + rr;
+  const uint64_t m = l ? (~(X.m[0] & X.m[1] & X.m[2]) & ((1ull << l) - 1)) : 0ull;
+  if (!m) return 0;
+  const int zl = 63 - __builtin_clzll(m);
+  const int rr = !((X.m[2] >> zl) & 1) ? 2 : (!((X.m[1] >> zl) & 1) ? 1 : 0);
+  return 3 * zl + rr;
+}
+__device__ __forceinline__ void tri_set_range(Tri& V, int lo, int hi) {   // positions lo..hi inclusive
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    if (hi < rr) continue;
+    const int la = (lo + 2 - rr) / 3, lb = (hi - rr) / 3;
+    if (la > lb) continue;
+    const uint64_t upto = lb >= 63 ? ~0ull : ((2ull << lb) - 1);
+    V.m[rr] |= upto & (~0ull << la);
+  }
+}
+// SPEC §3 on residue-interleaved masks, read strand (same arithmetic as walk_masks)
+__device__ __forceinline__ int tri_walk(const Tri& H, const Tri& R, const Tri& LX, int L, int K, Tri& V) {
+  V.m[0] = V.m[1] = V.m[2] = 0;
+  const int last = L - K;
+  int p = tri_ffs_stride3(H, 0);
+  if (p < 0) return 0;
+  int cov = 0;
+  if (p >= L / 5 && p > 0) {
+    const int z = tri_flz_upto(LX, p);
+    const int t = p - z;
+    if (t > 0) { cov += t; tri_set_range(V, p - t, p - 1); }
+  }
+  for (;;) {
+    const int e = tri_ffz_from(R, p);
+    cov += K + (e - p);
+    tri_set_range(V, p, e);
+    const int b = e + K;
+    if (b > last) break;
+    p = tri_ffs_stride3(H, b);
+    if (p < 0) break;
+  }
+  return cov;
+}
+// reverse-complement strand, walked downwards over read positions (same arithmetic as walk_masks_down)
+__device__ __forceinline__ int tri_walk_down(const Tri& H, const Tri& R, const Tri& LX, int L, int K, Tri& V) {
+  V.m[0] = V.m[1] = V.m[2] = 0;
+  const int last = L - K;
+  int ip = tri_fls_stride3_down(H, last);
+  if (ip < 0) return 0;
+  int cov = 0;
+  const int pj = last - ip;
+  if (pj >= L / 5 && pj > 0) {
+    const int z = tri_ffz_from(LX, ip);
+    const int t = z - ip;
+    if (t > 0) { cov += t; tri_set_range(V, ip + 1, ip + t); }
+  }
+  for (;;) {
+    const int ei = tri_flz_upto(R, ip);
+    cov += K + (ip - ei);
+    tri_set_range(V, ei, ip);
+    const int bj = (last - ei) + K;
+    if (bj > last) break;
+    ip = tri_fls_stride3_down(H, last - bj);
+    if (ip < 0) break;
+  }
+  return cov;
+}
+
+// The part of a packed record one lane of the three-per-lane front end needs: 32 bases and their N bits starting at base
+// 3*lane, plus the base before. Loaded one read AHEAD (the kernel prefetches the next record while it works on the
+// current one), which takes the HBM-cold record fetch out of the per-read dependency chain.
+struct TriRec { uint64_t W, NW; uint32_t prevb0; bool prevok0; };
+
+__device__ __forceinline__ TriRec tri_load_record(const uint64_t* __restrict__ rp, int nwb, int L, int K, int lane) {
+  TriRec t; t.W = 0; t.NW = 0; t.prevb0 = 0; t.prevok0 = false;
+  const int P = L - K + 1, nwn = (nwb + 1) >> 1, i0 = 3 * lane;
+  const uint64_t* __restrict__ np = rp + nwb;
+  if (i0 < P) {
+    const int wi = i0 >> 5, sh = (i0 & 31) * 2;
+    const uint64_t lo = rp[wi], hi = rp[wi + 1];           // wi + 1 <= nwb: still inside this read's record
+    t.W = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;       // bases i0 .. i0+31
+    const int nwi = i0 >> 6, nsh = i0 & 63;
+    const uint64_t nlo = np[nwi], nhi = (nwi + 1 < nwn) ? np[nwi + 1] : 0ull;
+    t.NW = nsh ? ((nlo >> nsh) | (nhi << (64 - nsh))) : nlo;  // N bits of bases i0 ..
+    if (i0 >= 1) { const int j = i0 - 1; t.prevb0 = (uint32_t)(rp[j >> 5] >> ((j & 31) * 2)) & 3u; t.prevok0 = !((np[j >> 6] >> (j & 63)) & 1); }
+  }
+  return t;
+}
+
+// Front end for 129..192 positions, k <= 29, in two halves so that the kernel can issue the NEXT read's record loads
+// between them: tri_issue prepares the three k-mers of the lane and issues their bucket loads; tri_finish consumes the
+// buckets, builds the masks, walks both strands and fills Strand<3> with w[r] / col[r] indexed by RESIDUE r.
+// (vmcnt retires in issue order: record loads issued BEFORE the bucket loads would make the bucket wait include the
+// HBM-cold record fetch; issued after, they overlap the mask/walk work.)
+struct TriProbe { uint64_t canon[3]; uint32_t bk[3]; uint32_t meta[3]; uint4 ka[3], kb[3]; };
+
+__device__ __forceinline__ void tri_issue(const DevIndex& ix, const TriRec& rec, int L, int lane, TriProbe& q) {
+  const int K = ix.K, P = L - K + 1;
+  const int i0 = 3 * lane;
+  const uint64_t W = rec.W, NW = rec.NW; const uint32_t prevb0 = rec.prevb0; const bool prevok0 = rec.prevok0;
+  const uint64_t kmask = (1ull << (2 * K)) - 1, nkmask = (1ull << K) - 1;
+  const uint64_t RCW = rc_kmer(W & ((1ull << (2 * (K + 2))) - 1), K + 2);   // one reverse complement for the three k-mers
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int i = i0 + r;
+    const bool validk = (i < P) && (((NW >> r) & nkmask) == 0);
+    const uint64_t x = (W >> (2 * r)) & kmask;
+    const bool next_ok = (i + K < L) && !((NW >> (K + r)) & 1);
+    const uint32_t nextb = (uint32_t)(W >> (2 * (K + r))) & 3u;
+    const uint32_t prevb = r ? ((uint32_t)(W >> (2 * (r - 1))) & 3u) : prevb0;
+    const bool prev_ok = r ? !((NW >> (r - 1)) & 1) : prevok0;
+    const uint64_t y = (RCW >> (2 * (2 - r))) & kmask;
+    const uint64_t c = x < y ? x : y;
+    q.canon[r] = c;
+    q.bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;
+    q.meta[r] = (validk ? 1u : 0u) | ((x != c) ? 2u : 0u) | (next_ok ? 4u : 0u) | (nextb << 3) | (prev_ok ? 32u : 0u) | (prevb << 6);
+  }
+  const Bucket* __restrict__ B = ix.buckets;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { const uint4* kp = reinterpret_cast<const uint4*>(&B[q.bk[r]]); q.ka[r] = kp[0]; q.kb[r] = kp[1]; }
+}
+
+__device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q, int L, int lane, Strand<3>& F, Strand<3>& R) {
+  const int K = ix.K;
+  const Bucket* __restrict__ B = ix.buckets;
+  const uint64_t* canon = q.canon; const uint32_t* bk = q.bk; const uint32_t* meta = q.meta; const uint4* ka = q.ka; const uint4* kb = q.kb;
+  uint32_t payF[3], payR[3]; bool ovf[3]; bool any_ovf = false;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const uint64_t k0 = ((uint64_t)ka[r].y << 32) | ka[r].x, k1 = ((uint64_t)kb[r].y << 32) | kb[r].x;
+    const bool valid = meta[r] & 1u, o = meta[r] & 2u;
+    const bool m0 = (k0 & KEY_MASK) == canon[r], m1 = k1 == canon[r];
+    const bool found = valid && (m0 || m1);
+    ovf[r] = valid && !found && (k0 >> 63);
+    any_ovf |= ovf[r];
+    const uint32_t p0 = m0 ? ka[r].z : kb[r].z, p1 = m0 ? ka[r].w : kb[r].w;
+    payF[r] = found ? (o ? p1 : p0) : PAY_ABSENT;
+    payR[r] = found ? (o ? p0 : p1) : PAY_ABSENT;
+  }
+  if (__ballot(any_ovf)) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      uint32_t b = bk[r]; bool pending = ovf[r];
+      while (pending) {
+        b = (b + 1 == ix.hash.n_buckets) ? 0u : b + 1;
+        uint32_t p0, p1; bool more;
+        if (probe_bucket(B, b, canon[r], p0, p1, more)) { const bool o = meta[r] & 2u; payF[r] = o ? p1 : p0; payR[r] = o ? p0 : p1; pending = false; }
+        else pending = more;
+      }
+    }
+  }
+  Tri HF, RF, LF, HR, RR, LR;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
+    const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
+    const bool hF = payF[r] != PAY_ABSENT, hR = payR[r] != PAY_ABSENT;
+    F.col[r] = payF[r] >> 10; R.col[r] = payR[r] >> 10;
+    HF.m[r] = __ballot(hF);
+    RF.m[r] = __ballot(hF && next_ok && ((payF[r] >> nextb) & 1u));
+    LF.m[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
+    HR.m[r] = __ballot(hR);
+    RR.m[r] = __ballot(hR && prev_ok && ((payR[r] >> (3u - prevb)) & 1u));
+    LR.m[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
+  }
+  Tri VF, VR;
+  F.cov = (HF.m[0] | HF.m[1] | HF.m[2]) ? tri_walk(HF, RF, LF, L, K, VF) : 0;
+  R.cov = (HR.m[0] | HR.m[1] | HR.m[2]) ? tri_walk_down(HR, RR, LR, L, K, VR) : 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { F.V.w[r] = F.cov ? VF.m[r] : 0ull; R.V.w[r] = R.cov ? VR.m[r] : 0ull; }
+}
+
 // Step 4: eq = AND of the colour rows of the visited positions. acc[t] (lane l) = word l + 64 t. Returns |eq|.
 template <int NR, int TW>
 __device__ __forceinline__ uint32_t intersect_visited(const DevIndex& ix, const Strand<NR>& S, int lane, uint64_t (&acc)[TW]) {
@@ -525,19 +738,20 @@ __device__ __forceinline__ uint32_t intern_class(const DevClasses& ct, int W, in
 }
 
 // SPEC §4 checks 1-2 on a mapped strand (cheap part): returns 0 if it may be valid, else the reason.
-__device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) {
+__device__ __forceinline__ int cheap_reason_p(int cov, int pmin, const BatchArgs& a) {
   if (cov == 0) return NB_NO_HIT;
   if (cov < a.score_threshold) return NB_SCORE_THRESHOLD;
-  if (cov < (int)a.pct_min[L]) return NB_SCORE_PERCENT;
+  if (cov < pmin) return NB_SCORE_PERCENT;
   return 0;
 }
+__device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) { return cheap_reason_p(cov, (int)a.pct_min[L], a); }
 
 // ------------------------------------------------------------------------------------------------------------
 // single-end kernel: one read per wave, grid-stride over the batch.
 #ifndef NB_SE_WAVES_PER_EU
 #define NB_SE_WAVES_PER_EU 1, 6   // measured on MI355X (10M x 150bp, 1k seqs): 6 waves/SIMD 23.4 ms, 7 -> 28.1, 8 -> 25.5:
 #endif                             // the kernel is bound by L2-miss request rate, more waves only thrash L2
-template <int NR, int TW>
+template <int NR, int TW, bool TRI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ct, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
@@ -545,14 +759,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  for (long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave; r < a.n; r += nwaves) {
-    int L = a.lens ? (int)a.lens[r] : a.max_len;
-    if (L > a.max_len) L = a.max_len;   // never index past the packed record
+  const long long r0 = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  TriRec nxt{}; int Lnxt = 0;
+  if constexpr (TRI) {
+    if (r0 < a.n) {
+      Lnxt = a.lens ? (int)a.lens[r0] : a.max_len; if (Lnxt > a.max_len) Lnxt = a.max_len;
+      if (Lnxt >= ix.K) nxt = tri_load_record(reads_ro + (size_t)r0 * a.stride, a.nwb, Lnxt, ix.K, lane);
+    }
+  }
+  for (long long r = r0; r < a.n; r += nwaves) {
+    int L;
+    TriRec rec{};
+    if constexpr (TRI) {
+      L = Lnxt; rec = nxt;
+    } else {
+      L = a.lens ? (int)a.lens[r] : a.max_len;
+      if (L > a.max_len) L = a.max_len;   // never index past the packed record
+    }
+    const int pmin = a.lens ? (int)a.pct_min[L] : a.pct_fixed;
     int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0; uint32_t cls = NB_NO_CLASS; int covF = 0, covR = 0;
+    auto prefetch_next = [&]() {
+      const long long rn = r + nwaves;
+      if (rn < a.n) {
+        Lnxt = a.lens ? (int)a.lens[rn] : a.max_len; if (Lnxt > a.max_len) Lnxt = a.max_len;
+        if (Lnxt >= ix.K) nxt = tri_load_record(reads_ro + (size_t)rn * a.stride, a.nwb, Lnxt, ix.K, lane);
+      }
+    };
+    if (TRI && L < ix.K) prefetch_next();
     if (L >= ix.K) {
-      const uint64_t* __restrict__ rp = reads_ro + (size_t)r * a.stride;   // separate noalias kernel argument: lets the
-      Strand<NR> SF, SR;                                                    // compiler fetch the record with scalar loads
-      map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR);
+      Strand<NR> SF, SR;
+      if constexpr (TRI) {                                                  // 129..192 positions: three per lane
+        TriProbe q;
+        tri_issue(ix, rec, L, lane, q);
+        prefetch_next();                              // this wave's next record, issued BEHIND the bucket loads
+        tri_finish(ix, q, L, lane, SF, SR);
+      } else {
+        const uint64_t* __restrict__ rp = reads_ro + (size_t)r * a.stride;   // separate noalias kernel argument: lets the
+        map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR);           // compiler fetch the record with scalar loads
+      }
       covF = SF.cov; covR = SR.cov;
       // candidates in preference order: larger coverage first, tie -> F   (SPEC §4 "Chosen orientation")
       const bool first_is_R = covR > covF;
@@ -561,7 +805,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
       for (int c = 0; c < 2 && !called; ++c) {
         const bool isR = (c == 0) ? first_is_R : !first_is_R;
         const int cov = isR ? covR : covF;
-        int rs = cheap_reason(cov, L, a);
+        int rs = cheap_reason_p(cov, pmin, a);
         if (rs == 0) {
 #if defined(NB_ABLATE) && NB_ABLATE >= 2
           acc[0] = (uint64_t)(isR ? SR.col[0] : SF.col[0]); const uint32_t n = 1;   // timing-only build: no intersection
@@ -850,7 +1094,7 @@ struct nb_ctx {
   // class table
   nb::DevClasses ct{}; int64_t max_classes = 0;
   // score_percent table
-  uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0;
+  uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0; std::vector<uint16_t> pct_host;
 };
 
 using namespace nb;
@@ -866,7 +1110,7 @@ static int ensure_pct_table(nb_ctx* c, double score_percent, int max_len, hipStr
   NB_HIP(hipMalloc((void**)&c->d_pct, t.size() * 2));
   NB_HIP(hipMemcpyAsync(c->d_pct, t.data(), t.size() * 2, hipMemcpyHostToDevice, stream));
   NB_HIP(hipStreamSynchronize(stream));
-  c->pct_len = max_len + 1; c->pct_value = score_percent; return NB_OK;
+  c->pct_len = max_len + 1; c->pct_value = score_percent; c->pct_host = t; return NB_OK;
 }
 
 // Persistent-style grid: as many 256-thread blocks as are co-resident (occupancy query x CUs), every wave strides over
@@ -882,13 +1126,13 @@ static int resident_blocks(nb_ctx* c, K kernel, long long n_templates) {
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
-template <int NR, int TW>
+template <int NR, int TW, bool TRI>
 static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
   static thread_local int cached_blocks = 0; static thread_local int cached_cu = 0;
-  if (!cached_blocks || cached_cu != c->n_cu) { cached_blocks = resident_blocks(c, nb_align_se_kernel<NR, TW>, 1ll << 40); cached_cu = c->n_cu; }
+  if (!cached_blocks || cached_cu != c->n_cu) { cached_blocks = resident_blocks(c, nb_align_se_kernel<NR, TW, TRI>, 1ll << 40); cached_cu = c->n_cu; }
   long long blocks = cached_blocks; const long long need = (a.n + 3) / 4;
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a, a.reads);
+  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW, TRI>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a, a.reads);
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
@@ -912,14 +1156,18 @@ static int dispatch_general(nb_ctx* c, int nr, const DevIndex& ix, const BatchAr
   }
 }
 
+// three-positions-per-lane front end: 129..192 positions and k <= 29 (window of k+3 bases in one 64-bit word)
+static bool use_tri(int positions, int k) { return positions > 128 && positions <= 192 && k <= 29; }
+
 template <int TW>
-static int dispatch_se(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
+static int dispatch_se(nb_ctx* c, int nr, int positions, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
+  if (use_tri(positions, ix.K)) return launch_se<3, TW, true>(c, ix, a, s);
   switch (nr) {
-    case 1: return launch_se<1, TW>(c, ix, a, s);
-    case 2: return launch_se<2, TW>(c, ix, a, s);
-    case 3: return launch_se<3, TW>(c, ix, a, s);
-    case 4: return launch_se<4, TW>(c, ix, a, s);
-    default: return launch_se<5, TW>(c, ix, a, s);
+    case 1: return launch_se<1, TW, false>(c, ix, a, s);
+    case 2: return launch_se<2, TW, false>(c, ix, a, s);
+    case 3: return launch_se<3, TW, false>(c, ix, a, s);
+    case 4: return launch_se<4, TW, false>(c, ix, a, s);
+    default: return launch_se<5, TW, false>(c, ix, a, s);
   }
 }
 
@@ -1062,14 +1310,14 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   a.reads = d_reads; a.lens = d_lens; a.max_len = max_len; a.stride = (int)nb_packed_stride_words(max_len); a.nwb = (max_len + 31) / 32;
   a.mates = d_mates; a.mate_lens = d_mate_lens; a.mate_max_len = mate_max_len;
   a.mstride = mate_max_len > 0 ? (int)nb_packed_stride_words(mate_max_len) : 0; a.mnwb = (mate_max_len + 31) / 32;
-  a.n = n; a.out_class = d_out_class; a.out_info = d_out_info; a.out_cov = d_out_cov; a.pct_min = c->d_pct;
+  a.n = n; a.out_class = d_out_class; a.out_info = d_out_info; a.out_cov = d_out_cov; a.pct_min = c->d_pct; a.pct_fixed = c->pct_host[(size_t)max_len];
   a.score_threshold = cfg->score_threshold; a.score_filter = cfg->score_filter; a.num_mismatches = cfg->num_mismatches;
   a.discard_multiple = cfg->discard_multiple_matches; a.intersect_level = cfg->intersect_level;
   a.require_valid_pair = cfg->require_valid_pair; a.strand_filter = cfg->strand_filter;
   const int nr = positions < 1 ? 1 : (positions + 63) / 64;
   if (d_mates || cfg->num_mismatches > 0)   // pairs and tolerated mismatches take the general (eager, LDS-staged) kernel
     return (c->W <= 64) ? dispatch_general<1>(c, nr, ix, a, s) : dispatch_general<4>(c, nr, ix, a, s);
-  return (c->W <= 64) ? dispatch_se<1>(c, nr, ix, a, s) : dispatch_se<4>(c, nr, ix, a, s);
+  return (c->W <= 64) ? dispatch_se<1>(c, nr, positions, ix, a, s) : dispatch_se<4>(c, nr, positions, ix, a, s);
 }
 
 int32_t nb_classes_count(nb_ctx* c, int64_t* n) {
@@ -1116,7 +1364,8 @@ int32_t nb_counts_device_ptr(nb_ctx* c, void** d_counts, int64_t* capacity) {
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired) {
   static thread_local char buf[96];
   const int positions = max_len - k + 1; const int nr = positions < 1 ? 1 : (positions + 63) / 64; const int W = (n_seqs + 63) / 64;
-  std::snprintf(buf, sizeof buf, "nb_align_%s_kernel<%d, %d>", paired ? "general" : "se", nr > 5 ? 5 : nr, W <= 64 ? 1 : 4);
+  if (paired) std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d>", nr > 5 ? 5 : nr, W <= 64 ? 1 : 4);
+  else std::snprintf(buf, sizeof buf, "nb_align_se_kernel<%d, %d, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? "true" : "false");
   return buf;
 }
 

@@ -27,7 +27,8 @@ def test_python_binding_covers_header(built):
     lib = _lib.lib()
     assert lib.nb_version() == 1
     assert lib.nb_packed_stride_words(150) == 8          # 5 base words + 3 N-mask words = 64 B per 150-bp read
-    assert lib.nb_kernel_name(150, 20, 1000, 0) == b"nb_align_se_kernel<3, 1>"
+    assert lib.nb_kernel_name(150, 20, 1000, 0) == b"nb_align_se_kernel<3, 1, true>"
+    assert lib.nb_kernel_name(91, 20, 1000, 0) == b"nb_align_se_kernel<2, 1, false>"
 
 
 def test_no_gpu_is_a_loud_error(built):
