@@ -97,3 +97,19 @@ def test_general_kernel_ragged_pairs(built):
     gpu = run_gpu(engine.Index(strs, 20), cfg, w1, n1, 160, mate_words=w2, mate_lens=n2, mate_max_len=130)
     ora = oracle.OracleIndex(strs, 20).align_strs(cfg, r1s, r2s, n_threads=4)
     assert_same(gpu, ora, "ragged pairs")
+
+
+def test_dictionary_agreement_ops_on_gpu(built):
+    """The torch ops the multi-rank reduce runs on the GPU (unique / scatter_reduce / index_add on int64) behave as on CPU."""
+    import torch
+    from nimble_amd import distributed
+    rng = np.random.default_rng(5)
+    base = rng.integers(-2**62, 2**62, size=(5000, 16))
+    R = np.concatenate([base, base[:1700], base[300:900]])
+    g_cpu, i_cpu = distributed._agree(torch.from_numpy(R))
+    g_gpu, i_gpu = distributed._agree(torch.from_numpy(R).cuda())
+    assert g_gpu.is_cuda and bool((g_gpu[i_gpu].cpu() == torch.from_numpy(R)).all())
+    assert {tuple(r) for r in g_gpu.cpu().tolist()} == {tuple(r) for r in g_cpu.tolist()} and g_gpu.shape[0] == 5000
+    dense = torch.zeros(g_gpu.shape[0], dtype=torch.int64, device="cuda")
+    dense.index_add_(0, i_gpu[:5000], torch.ones(5000, dtype=torch.int64, device="cuda"))
+    assert int(dense.sum()) == 5000 and int(dense.max()) == 1
