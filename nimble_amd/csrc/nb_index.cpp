@@ -135,6 +135,24 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     for (uint64_t t = col_off[c]; t < col_off[c + 1]; ++t) row[pool[t] >> 6] |= 1ull << (pool[t] & 63);
   }
 
+  // 3b. device form of the colours: span descriptors + packed spans for the wide ones (nb_internal.h, ColDesc)
+  ix->desc.resize(n_col);
+  ix->packed.assign(1, 0ull);
+  for (uint32_t id = 0; id < n_col; ++id) {
+    const uint64_t* row = ix->eq_rows.data() + (size_t)id * (size_t)ix->words;
+    int first = 0, lastw = ix->words - 1;
+    while (first < ix->words && row[first] == 0) ++first;
+    while (lastw > first && row[lastw] == 0) --lastw;
+    ColDesc d{}; d.w0 = (uint32_t)first; d.nw = (uint32_t)(lastw - first + 1); d.size = ix->eq_sizes[id];
+    d.m0 = row[first]; d.m1 = d.nw > 1 ? row[first + 1] : 0ull; d.off = 0;
+    if (d.nw > 2) {
+      if (ix->packed.size() + d.nw > 0xFFFFFFFFull) { delete ix; set_error("nb_index_build: packed colour spans exceed 2^32 words"); return NB_ERR_UNSUPPORTED; }
+      d.off = (uint32_t)ix->packed.size();
+      ix->packed.insert(ix->packed.end(), row + first, row + lastw + 1);
+    }
+    ix->desc[id] = d;
+  }
+
   // 4. unitig-interior flags (SPEC §2, local rule). recs is sorted by k-mer.
   for (auto& r : recs) {
     if (__builtin_popcount(r.rext) == 1) {

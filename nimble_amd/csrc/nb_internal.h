@@ -55,6 +55,19 @@ NB_HD inline uint32_t kmer_bucket(uint64_t canon, const KmerHash& h) {
   return (uint32_t)(((uint64_t)(m * 0x2C1B3C6Du) * (uint64_t)h.n_buckets) >> 32);
 }
 
+// A colour (equivalence class of the graph) on the device: the span of u64 words of its bitset that can be non-zero,
+// with the first two words inline. Most classes of a gene-family library live inside one locus, i.e. inside one or two
+// words, so the intersection of a read's classes usually needs nothing but these 32 bytes per k-mer position; wider
+// classes keep their span in `packed` at [off, off + nw). Loaded with two dwordx4.
+struct ColDesc {
+  uint32_t w0;     // first word of the span
+  uint32_t nw;     // words in the span (>= 1)
+  uint32_t off;    // index into packed[] of the span (valid when nw > 2)
+  uint32_t size;   // members (popcount)
+  uint64_t m0, m1; // words w0 and w0 + 1
+};
+static_assert(sizeof(ColDesc) == 32, "descriptor must be 32 bytes");
+
 inline uint32_t make_payload(uint32_t colour, uint32_t lext, uint32_t rext, uint32_t r_int, uint32_t l_int) {
   return (colour << 10) | (l_int << 9) | (r_int << 8) | (lext << 4) | rext;
 }
@@ -76,8 +89,10 @@ struct HostIndex {
   int64_t n_kmers = 0;                // distinct stranded k-mers
   int64_t n_canonical = 0;
   std::vector<Bucket> buckets;        // hash.n_buckets
-  std::vector<uint64_t> eq_rows;      // n_colours * words; colour ids ascend by set size
+  std::vector<uint64_t> eq_rows;      // n_colours * words, dense bitsets (HOST only: nb_index_query, tests)
   std::vector<uint32_t> eq_sizes;     // n_colours
+  std::vector<ColDesc> desc;          // n_colours descriptors (device)
+  std::vector<uint64_t> packed;       // spans of the colours wider than two words (device)
   // device copies (owned by the ctx that uploaded; recorded here for stats)
   int uploaded = 0;
 };
