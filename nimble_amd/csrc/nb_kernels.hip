@@ -503,101 +503,103 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
 // col[r] simply mean "residue r" instead of "round r".
 struct Tri { uint64_t m[3]; };
 
-__device__ __forceinline__ bool tri_bit(const Tri& t, int l, int r) {
-  const uint64_t w = r == 0 ? t.m[0] : (r == 1 ? t.m[1] : t.m[2]);
-  return (w >> l) & 1;
+// Positions are kept as (lane, residue) pairs so the walk never divides by three; lin() gives the linear position.
+struct TPos { int l, r; };
+__device__ __forceinline__ int lin(TPos p) { return 3 * p.l + p.r; }
+__device__ __forceinline__ uint64_t tri_word(const Tri& t, int r) { return r == 0 ? t.m[0] : (r == 1 ? t.m[1] : t.m[2]); }
+__device__ __forceinline__ TPos tpos_add(TPos p, int dq, int dr) {   // p + (3 dq + dr), 0 <= dr < 3
+  int r = p.r + dr, l = p.l + dq;
+  if (r >= 3) { r -= 3; ++l; }
+  return TPos{l, r};
 }
-// first position >= from with residue from % 3 whose bit is set, or -1
-__device__ __forceinline__ int tri_ffs_stride3(const Tri& H, int from) {
-  const int l0 = from / 3, r = from - 3 * l0;
-  const uint64_t w = r == 0 ? H.m[0] : (r == 1 ? H.m[1] : H.m[2]);
-  const uint64_t m = w >> l0;
-  return m ? 3 * (l0 + __builtin_ctzll(m)) + r : -1;
+__device__ __forceinline__ TPos tpos_sub(TPos p, int dq, int dr) {   // p - (3 dq + dr); l < 0 when the result is negative
+  int r = p.r - dr, l = p.l - dq;
+  if (r < 0) { r += 3; --l; }
+  return TPos{l, r};
 }
-// last position <= from with residue from % 3 whose bit is set, or -1
-__device__ __forceinline__ int tri_fls_stride3_down(const Tri& H, int from) {
-  const int l0 = from / 3, r = from - 3 * l0;
-  const uint64_t w = r == 0 ? H.m[0] : (r == 1 ? H.m[1] : H.m[2]);
-  const uint64_t m = l0 >= 63 ? w : (w & ((2ull << l0) - 1));
-  return m ? 3 * (63 - __builtin_clzll(m)) + r : -1;
+// first position >= from with from's residue whose bit is set; l = -1 if none
+__device__ __forceinline__ TPos tri_ffs_stride3(const Tri& H, TPos from) {
+  const uint64_t m = from.l >= 64 ? 0ull : (tri_word(H, from.r) >> from.l);
+  return TPos{m ? from.l + __builtin_ctzll(m) : -1, from.r};
+}
+// last position <= from with from's residue whose bit is set; l = -1 if none
+__device__ __forceinline__ TPos tri_fls_stride3_down(const Tri& H, TPos from) {
+  const uint64_t w = tri_word(H, from.r);
+  const uint64_t m = from.l >= 63 ? w : (w & ((2ull << from.l) - 1));
+  return TPos{m ? 63 - __builtin_clzll(m) : -1, from.r};
 }
 // first position >= p whose bit is ZERO (a zero is guaranteed at or before position 191)
-__device__ __forceinline__ int tri_ffz_from(const Tri& X, int p) {
-  const int l = p / 3, r = p - 3 * l;
+__device__ __forceinline__ TPos tri_ffz_from(const Tri& X, TPos p) {
 #pragma unroll
-  for (int rr = 0; rr < 3; ++rr) if (rr >= r && !((X.m[rr] >> l) & 1)) return 3 * l + rr;
-  if (l >= 63) return 192;
-  const uint64_t m = ~(X.m[0] & X.m[1] & X.m[2]) >> (l + 1);
-  if (!m) return 192;
-  const int zl = l + 1 + __builtin_ctzll(m);
-  const int rr = !((X.m[0] >> zl) & 1) ? 0 : (!((X.m[1] >> zl) & 1) ? 1 : 2);
-  return 3 * zl + rr;
+  for (int rr = 0; rr < 3; ++rr) if (rr >= p.r && !((X.m[rr] >> p.l) & 1)) return TPos{p.l, rr};
+  if (p.l >= 63) return TPos{64, 0};
+  const uint64_t m = ~(X.m[0] & X.m[1] & X.m[2]) >> (p.l + 1);
+  if (!m) return TPos{64, 0};
+  const int zl = p.l + 1 + __builtin_ctzll(m);
+  return TPos{zl, !((X.m[0] >> zl) & 1) ? 0 : (!((X.m[1] >> zl) & 1) ? 1 : 2)};
 }
 // last position <= p whose bit is ZERO (position 0 is guaranteed zero in the masks passed here)
-__device__ __forceinline__ int tri_flz_upto(const Tri& X, int p) {
-  const int l = p / 3, r = p - 3 * l;
+__device__ __forceinline__ TPos tri_flz_upto(const Tri& X, TPos p) {
 #pragma unroll
-  for (int rr = 2; rr >= 0; --rr) if (rr <= r && !((X.m[rr] >> l) & 1)) return 3 * l + rr;
-  const uint64_t m = l ? (~(X.m[0] & X.m[1] & X.m[2]) & ((1ull << l) - 1)) : 0ull;
-  if (!m) return 0;
+  for (int rr = 2; rr >= 0; --rr) if (rr <= p.r && !((X.m[rr] >> p.l) & 1)) return TPos{p.l, rr};
+  const uint64_t m = p.l ? (~(X.m[0] & X.m[1] & X.m[2]) & ((1ull << p.l) - 1)) : 0ull;
+  if (!m) return TPos{0, 0};
   const int zl = 63 - __builtin_clzll(m);
-  const int rr = !((X.m[2] >> zl) & 1) ? 2 : (!((X.m[1] >> zl) & 1) ? 1 : 0);
-  return 3 * zl + rr;
+  return TPos{zl, !((X.m[2] >> zl) & 1) ? 2 : (!((X.m[1] >> zl) & 1) ? 1 : 0)};
 }
-__device__ __forceinline__ void tri_set_range(Tri& V, int lo, int hi) {   // positions lo..hi inclusive
+__device__ __forceinline__ void tri_set_range(Tri& V, TPos a, TPos b) {   // positions a..b inclusive, lin(a) <= lin(b)
 #pragma unroll
   for (int rr = 0; rr < 3; ++rr) {
-    if (hi < rr) continue;
-    const int la = (lo + 2 - rr) / 3, lb = (hi - rr) / 3;
+    const int la = a.l + (rr < a.r ? 1 : 0), lb = b.l - (rr > b.r ? 1 : 0);
     if (la > lb) continue;
     const uint64_t upto = lb >= 63 ? ~0ull : ((2ull << lb) - 1);
     V.m[rr] |= upto & (~0ull << la);
   }
 }
-// SPEC §3 on residue-interleaved masks, read strand (same arithmetic as walk_masks)
-__device__ __forceinline__ int tri_walk(const Tri& H, const Tri& R, const Tri& LX, int L, int K, Tri& V) {
+// SPEC §3 on residue-interleaved masks, read strand (same arithmetic as walk_masks); kq, kr = K / 3, K % 3
+__device__ __forceinline__ int tri_walk(const Tri& H, const Tri& R, const Tri& LX, int L, int K, int kq, int kr, Tri& V) {
   V.m[0] = V.m[1] = V.m[2] = 0;
   const int last = L - K;
-  int p = tri_ffs_stride3(H, 0);
-  if (p < 0) return 0;
+  TPos p = tri_ffs_stride3(H, TPos{0, 0});
+  if (p.l < 0) return 0;
   int cov = 0;
-  if (p >= L / 5 && p > 0) {
-    const int z = tri_flz_upto(LX, p);
-    const int t = p - z;
-    if (t > 0) { cov += t; tri_set_range(V, p - t, p - 1); }
+  if (lin(p) >= L / 5 && lin(p) > 0) {
+    const TPos z = tri_flz_upto(LX, p);
+    const int t = lin(p) - lin(z);
+    if (t > 0) { cov += t; tri_set_range(V, z, tpos_sub(p, 0, 1)); }
   }
   for (;;) {
-    const int e = tri_ffz_from(R, p);
-    cov += K + (e - p);
+    const TPos e = tri_ffz_from(R, p);
+    cov += K + (lin(e) - lin(p));
     tri_set_range(V, p, e);
-    const int b = e + K;
-    if (b > last) break;
+    const TPos b = tpos_add(e, kq, kr);
+    if (lin(b) > last) break;
     p = tri_ffs_stride3(H, b);
-    if (p < 0) break;
+    if (p.l < 0) break;
   }
   return cov;
 }
 // reverse-complement strand, walked downwards over read positions (same arithmetic as walk_masks_down)
-__device__ __forceinline__ int tri_walk_down(const Tri& H, const Tri& R, const Tri& LX, int L, int K, Tri& V) {
+__device__ __forceinline__ int tri_walk_down(const Tri& H, const Tri& R, const Tri& LX, int L, int K, int kq, int kr, TPos plast, Tri& V) {
   V.m[0] = V.m[1] = V.m[2] = 0;
   const int last = L - K;
-  int ip = tri_fls_stride3_down(H, last);
-  if (ip < 0) return 0;
+  TPos ip = tri_fls_stride3_down(H, plast);
+  if (ip.l < 0) return 0;
   int cov = 0;
-  const int pj = last - ip;
+  const int pj = last - lin(ip);
   if (pj >= L / 5 && pj > 0) {
-    const int z = tri_ffz_from(LX, ip);
-    const int t = z - ip;
-    if (t > 0) { cov += t; tri_set_range(V, ip + 1, ip + t); }
+    const TPos z = tri_ffz_from(LX, ip);
+    const int t = lin(z) - lin(ip);
+    if (t > 0) { cov += t; tri_set_range(V, tpos_add(ip, 0, 1), z); }
   }
   for (;;) {
-    const int ei = tri_flz_upto(R, ip);
-    cov += K + (ip - ei);
+    const TPos ei = tri_flz_upto(R, ip);
+    cov += K + (lin(ip) - lin(ei));
     tri_set_range(V, ei, ip);
-    const int bj = (last - ei) + K;
-    if (bj > last) break;
-    ip = tri_fls_stride3_down(H, last - bj);
-    if (ip < 0) break;
+    const TPos tgt = tpos_sub(ei, kq, kr);          // read position of the next rc seed scan: ei - K
+    if (tgt.l < 0) break;
+    ip = tri_fls_stride3_down(H, tgt);
+    if (ip.l < 0) break;
   }
   return cov;
 }
@@ -700,8 +702,9 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
     LR.m[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
   }
   Tri VF, VR;
-  F.cov = (HF.m[0] | HF.m[1] | HF.m[2]) ? tri_walk(HF, RF, LF, L, K, VF) : 0;
-  R.cov = (HR.m[0] | HR.m[1] | HR.m[2]) ? tri_walk_down(HR, RR, LR, L, K, VR) : 0;
+  const int kq = K / 3, kr = K - 3 * kq, last = L - K;
+  F.cov = (HF.m[0] | HF.m[1] | HF.m[2]) ? tri_walk(HF, RF, LF, L, K, kq, kr, VF) : 0;
+  R.cov = (HR.m[0] | HR.m[1] | HR.m[2]) ? tri_walk_down(HR, RR, LR, L, K, kq, kr, TPos{last / 3, last - 3 * (last / 3)}, VR) : 0;
 #pragma unroll
   for (int r = 0; r < 3; ++r) { F.V.w[r] = F.cov ? VF.m[r] : 0ull; R.V.w[r] = R.cov ? VR.m[r] : 0ull; }
 }
