@@ -8,7 +8,7 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnimble_amd.so")
 SOURCES = ["nb_kernels.hip", "nb_index.cpp", "nb_ingest.cpp", "nb_report.cpp", "nb_host.cpp"]
-HEADERS = [os.path.join(CSRC, "nb_internal.h"), os.path.join(REPO_ROOT, "include", "nimble_amd.h")]
+HEADERS = [os.path.join(CSRC, "nb_internal.h"), os.path.join(CSRC, "nb_wave.h"), os.path.join(REPO_ROOT, "include", "nimble_amd.h")]
 
 
 def _hipcc():

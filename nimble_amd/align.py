@@ -83,7 +83,7 @@ class LibraryRun:
         self.max_hits = int(c["max_hits_to_report"])
         self.multi_hits = int(c["discard_multi_hits"])
         self.index = engine.Index(self.lib.sequences, self.lib.k)
-        self.ctx = engine.Context(device_id, max_classes=1 << 20)
+        self.ctx = engine.Context(device_id, max_classes=1 << 22)
         self.ctx.upload(self.index)
         self.out_path = out_path
         self.per_read = per_read

@@ -22,6 +22,7 @@
 #include <string>
 
 #include "nb_internal.h"
+#include "nb_wave.h"
 
 namespace nb {
 
@@ -72,58 +73,6 @@ struct BatchArgs {
 
 // ------------------------------------------------------------------------------------------------------------
 // wave-level helpers (wave64)
-// Wave-wide reductions with a wave-UNIFORM result: four DPP row rotations reduce inside each row of 16 lanes (every
-// lane of a row ends up with the row's value), then four v_readlane + scalar ops combine the rows. No LDS traffic
-// (ds_bpermute) and no lgkmcnt waits. Must be called with all 64 lanes active (wave-uniform control flow).
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
-  // old = the source itself: with every lane enabled `old` is never selected, but passing 0 lets hipcc's DPP-combine fold
-  // it into v_min_u32_dpp with a wrong identity (observed on ROCm 7.2: wave_min returned 0)
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
-// NOTE each DPP move is evaluated ONCE into a temporary before the combining op: writing `cond ? dpp(v) : v` makes hipcc
-// re-issue the DPP move inside a divergent branch (partial EXEC), which reads stale lanes.
-struct OpMin { __device__ __forceinline__ static uint32_t f(uint32_t a, uint32_t b) { return a < b ? a : b; } };
-struct OpMax { __device__ __forceinline__ static uint32_t f(uint32_t a, uint32_t b) { return a > b ? a : b; } };
-struct OpAnd { __device__ __forceinline__ static uint32_t f(uint32_t a, uint32_t b) { return a & b; } };
-struct OpAdd { __device__ __forceinline__ static uint32_t f(uint32_t a, uint32_t b) { return a + b; } };
-template <class OP> __device__ __forceinline__ uint32_t row_reduce(uint32_t v) {
-  uint32_t t;
-  t = dpp_mov<0x121>(v); v = OP::f(v, t);
-  t = dpp_mov<0x122>(v); v = OP::f(v, t);
-  t = dpp_mov<0x124>(v); v = OP::f(v, t);
-  t = dpp_mov<0x128>(v); v = OP::f(v, t);
-  return v;
-}
-__device__ __forceinline__ uint32_t rows4(uint32_t v, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 16 * k); }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  v = row_reduce<OpMin>(v);
-  const uint32_t a = rows4(v, 0), b = rows4(v, 1), c = rows4(v, 2), d = rows4(v, 3);
-  const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
-  return ab < cd ? ab : cd;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-  v = row_reduce<OpMax>(v);
-  const uint32_t a = rows4(v, 0), b = rows4(v, 1), c = rows4(v, 2), d = rows4(v, 3);
-  const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-  return ab > cd ? ab : cd;
-}
-__device__ __forceinline__ uint32_t wave_and_u32(uint32_t v) {
-  v = row_reduce<OpAnd>(v);
-  return rows4(v, 0) & rows4(v, 1) & rows4(v, 2) & rows4(v, 3);
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-  v = row_reduce<OpAdd>(v);
-  return rows4(v, 0) + rows4(v, 1) + rows4(v, 2) + rows4(v, 3);
-}
-__device__ __forceinline__ uint64_t wave_and_u64(uint64_t v) {
-  return ((uint64_t)wave_and_u32((uint32_t)(v >> 32)) << 32) | wave_and_u32((uint32_t)v);
-}
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {   // mod 2^64: sum the halves separately, carry by hand
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  // low halves: 64 values < 2^32 sum to < 2^38: split into 16-bit limbs so 32-bit lane adds cannot overflow
-  const uint32_t s0 = wave_sum_u32(lo & 0xFFFFu), s1 = wave_sum_u32(lo >> 16), s2 = wave_sum_u32(hi & 0xFFFFu), s3 = wave_sum_u32(hi >> 16);
-  return (uint64_t)s0 + ((uint64_t)s1 << 16) + ((uint64_t)s2 << 32) + ((uint64_t)s3 << 48);
-}
 __device__ __forceinline__ uint64_t bcast_u64(uint64_t v) {  // lane 0's value to every lane
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
