@@ -137,6 +137,17 @@ int32_t nb_fastq_set_threads(nb_fastq* fq, int32_t threads);
 int32_t nb_fastq_next_batch(nb_fastq* fq, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
                             int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len, char* cbqual_out);
 
+/* ---- BAM input (host, zlib only): replaces the Rust binary's BAM decode for `--input x.bam` (__main__.py:171-175).
+ * No sort is needed (the reference sorts by UR only so that its aligner sees one UMI's records together,
+ * __main__.py:344-347; this engine emits one row per template and `report` groups them). r1/r2 are packed at
+ * nb_packed_stride_words(max_len); cb_out/ub_out receive the Z tags CB / UB of r1, tag_width bytes per template, NUL
+ * padded. *paired_out = 1 when the records are adjacent mates. *n_out = templates read (0 = end of file). ---- */
+typedef struct nb_bam nb_bam;
+int32_t nb_bam_open(const char* path, nb_bam** out);
+int32_t nb_bam_close(nb_bam* bam);
+int32_t nb_bam_next_batch(nb_bam* bam, int64_t max_templates, int32_t max_len, uint64_t* r1_words, uint16_t* r1_lens, uint64_t* r2_words,
+                          uint16_t* r2_lens, char* cb_out, char* ub_out, int32_t tag_width, int64_t* n_out, int32_t* paired_out);
+
 /* ---- 10x cell-barcode whitelist correction (host): restates correct_cell_barcode,
  * /root/reference/nimble/fastq_barcode_processor.py:73-128 (exact -> Hamming-1 candidates -> lowest quality at the
  * differing base; per-raw-barcode cache). raw/qual/out are fixed-width cb_len per record; ok[i] = 0 drops the pair

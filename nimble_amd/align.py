@@ -11,7 +11,9 @@ Input modes
   * two FASTQ(.gz) + tenx options: R1 carries CB+UMI (fastq_barcode_processor.py:131-141), R2 is aligned; one row per
     called read with r1_CB / r1_UB — what the reference obtains via `fastq-to-bam` + BAM input.
   * two FASTQ(.gz) without tenx options: a biological pair (needs the paired kernel).
-  * BAM: not available in this build (no htslib/pysam in the image) -> error, non-zero exit.
+  * one BAM (single-end or name-collated pairs with CB/UB tags): read with the built-in zlib BAM reader
+    (csrc/nb_bam.cpp), one row per called template; the reference's `samtools sort -t UR -n` staging (sort_input_bam,
+    __main__.py:312-370) is unnecessary because `report` groups by (cell, UMI) itself, so nothing is sorted or deleted.
 """
 import ctypes as ct
 import gzip
@@ -67,6 +69,32 @@ class FastqReader:
     def close(self):
         if self._h:
             _lib.lib().nb_fastq_close(self._h)
+            self._h = None
+
+
+class BamReader:
+    """nb_bam_* (csrc/nb_bam.cpp): templates of a BAM in file order, CB/UB tags of r1. No sort needed (see nb_bam.cpp)."""
+    TAG_WIDTH = 48
+
+    def __init__(self, path):
+        self._h = ct.c_void_p()
+        _lib.check(_lib.lib().nb_bam_open(path.encode(), ct.byref(self._h)))
+
+    def next_batch(self, max_reads, max_len):
+        stride = engine.packed_stride_words(max_len)
+        w1 = np.zeros((max_reads, stride), dtype=np.uint64); l1 = np.zeros(max_reads, dtype=np.uint16)
+        w2 = np.zeros((max_reads, stride), dtype=np.uint64); l2 = np.zeros(max_reads, dtype=np.uint16)
+        cb = np.zeros((max_reads, self.TAG_WIDTH), dtype="S1"); ub = np.zeros((max_reads, self.TAG_WIDTH), dtype="S1")
+        n, paired = ct.c_int64(), ct.c_int32()
+        _lib.check(_lib.lib().nb_bam_next_batch(self._h, max_reads, max_len, w1.ctypes.data, l1.ctypes.data, w2.ctypes.data, l2.ctypes.data,
+                                                cb.ctypes.data, ub.ctypes.data, self.TAG_WIDTH, ct.byref(n), ct.byref(paired)))
+        k = n.value
+        return {"n": k, "paired": bool(paired.value), "words": w1[:k], "lens": l1[:k], "mate_words": w2[:k], "mate_lens": l2[:k],
+                "cb": cb[:k], "umi": ub[:k]}
+
+    def close(self):
+        if self._h:
+            _lib.lib().nb_bam_close(self._h)
             self._h = None
 
 
@@ -179,9 +207,9 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         import torch
         print("Aligning input data to the reference libraries")
         sys.stdout.flush()
-        if os.path.splitext(input[0])[-1].lower() == ".bam":
-            raise NotImplementedError("BAM input needs htslib/pysam, which this image lacks; pass FASTQ (use the tenx options "
-                                      "for R1 barcode reads instead of `fastq-to-bam`)")
+        is_bam = os.path.splitext(input[0])[-1].lower() == ".bam"
+        if is_bam and len(input) != 1:
+            raise ValueError("--input takes exactly one BAM file")
         if len(input) > 2:
             raise ValueError("--input takes one or two FASTQ files")
         if strand_filter not in engine.STRAND_FILTERS:
@@ -191,22 +219,30 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         if not torch.cuda.is_available():
             raise RuntimeError("no MI355X/HIP device visible: nimble_amd has no CPU alignment path")
         dev = torch.device("cuda", device_id)
-        per_read = tenx is not None
-        if per_read and len(input) != 2:
+        per_read = tenx is not None or is_bam      # BAM input carries CB/UB tags: one row per called template, as the reference
+        if tenx is not None and is_bam:
+            raise ValueError("--tenx applies to FASTQ input; a BAM already carries its CB/UB tags")
+        if per_read and not is_bam and len(input) != 2:
             raise ValueError("tenx mode needs --input R1.fastq R2.fastq")
-        paired = len(input) == 2 and not per_read
+        paired = len(input) == 2 and not per_read   # (a paired BAM is detected from its flags, batch by batch)
         runs = []
         for lib in libs:
             suffix = "." + os.path.splitext(os.path.basename(lib))[0] if len(libs) > 1 else ""
             runs.append(LibraryRun(lib, append_path_string(output, suffix), strand_filter, device_id, per_read))
         corrector = None
-        if per_read and tenx.whitelist:
+        if tenx is not None and tenx.whitelist:
             corrector = NativeWhitelist(tenx.whitelist)
-        r1 = FastqReader(input[0], num_cores)
+        bam = BamReader(input[0]) if is_bam else None
+        r1 = FastqReader(input[0], num_cores) if not is_bam else None
         r2 = FastqReader(input[1], num_cores) if len(input) == 2 else None
         total, t0 = 0, time.time()
         while True:
-            if per_read:
+            if is_bam:
+                bb = bam.next_batch(min(batch_reads, 1 << 20), MAX_READ_LEN)
+                b1 = {"cb": bb["cb"], "umi": bb["umi"], "cbq": None}
+                seq = {"n": bb["n"], "words": bb["words"], "lens": bb["lens"]}
+                mate = {"n": bb["n"], "words": bb["mate_words"], "lens": bb["mate_lens"]} if bb["paired"] else None
+            elif per_read:
                 b1 = r1.next_batch(batch_reads, barcodes_only=True, cb_len=tenx.cb_length, umi_len=tenx.umi_length)
                 b2 = r2.next_batch(batch_reads, MAX_READ_LEN)
                 if b1["n"] != b2["n"]:
@@ -255,9 +291,9 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         if corrector:
             print(f"cell barcodes: {corrector.stats}")
         print(f"Aligned {total} templates in {time.time() - t0:.2f} s")
-        r1.close()
-        if r2:
-            r2.close()
+        for rd in (r1, r2, bam):
+            if rd:
+                rd.close()
         print("Retaining all input files.")
         return 0
     except Exception as e:  # exit-code convention of the process boundary (__main__.py:198,211)

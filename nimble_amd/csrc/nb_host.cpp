@@ -103,8 +103,9 @@ int32_t nb_format_tenx_rows(int64_t n, const uint32_t* cls, const uint32_t* info
     if (pos + (int64_t)fl + cb_len + umi_len + 64 > out_cap) { nb::set_error("nb_format_tenx_rows: output buffer too small"); return NB_ERR_OVERFLOW; }
     std::memcpy(out + pos, f, fl); pos += (int64_t)fl; out[pos++] = '\t';
     put_u((info[i] >> 25) & 3u); out[pos++] = '\t';
-    std::memcpy(out + pos, cb + i * cb_len, (size_t)cb_len); pos += cb_len; out[pos++] = '\t';
-    std::memcpy(out + pos, umi + i * umi_len, (size_t)umi_len); pos += umi_len;
+    const size_t cl = strnlen(cb + i * cb_len, (size_t)cb_len), ul = strnlen(umi + i * umi_len, (size_t)umi_len);   // fields may be NUL padded (BAM tags)
+    std::memcpy(out + pos, cb + i * cb_len, cl); pos += (int64_t)cl; out[pos++] = '\t';
+    std::memcpy(out + pos, umi + i * umi_len, ul); pos += (int64_t)ul;
     for (int j = 0; j < 4; ++j) { out[pos++] = '\t'; put_u((unsigned)((cov[i] >> (16 * j)) & 0xFFFF)); }
     out[pos++] = '\n'; ++rows;
   }

@@ -9,6 +9,8 @@
 // Why native: the reference's per-UMI Python loop (utils.py:125-131,158-165) is the slow part of `report`
 // (SURVEY.md §8f item 1); this streams the TSV once and reduces 10^8-row tables in minutes instead of hours.
 // Compiled with -ffp-contract=off: no fused multiply-add may alter the double arithmetic.
+#include <zlib.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -86,8 +88,11 @@ extern "C" {
 int32_t nb_report_tsv(const char* input_path, const char* output_path, double threshold, int32_t disable_thresholding, int64_t* status_out) {
   if (!input_path || !output_path || !status_out) { nb::set_error("nb_report_tsv: null argument"); return NB_ERR_INVALID; }
   status_out[0] = 0; status_out[1] = 0;
-  FILE* in = std::fopen(input_path, "rb");
+  // gzopen reads plain and gzip files alike: the reference's pd.read_csv infers gzip from a ".gz" name
+  // (/root/reference/nimble/__main__.py:219), which is what the aligner writes for BAM input
+  gzFile in = gzopen(input_path, "rb");
   if (!in) { nb::set_error(std::string("nb_report_tsv: cannot open ") + input_path); return NB_ERR_INVALID; }
+  gzbuffer(in, 1 << 20);
   auto write_empty = [&]() -> int32_t {
     FILE* o = std::fopen(output_path, "wb"); if (!o) { nb::set_error("nb_report_tsv: cannot write output"); return NB_ERR_INVALID; }
     std::fclose(o); status_out[0] = 1; return NB_OK;
@@ -136,7 +141,8 @@ int32_t nb_report_tsv(const char* input_path, const char* output_path, double th
   };
   bool any_bytes = false, any_body = false; int perr = 0;
   while (!eof && perr == 0) {
-    const size_t got = std::fread(buf.data() + have, 1, buf.size() - have, in);
+    const int gr = gzread(in, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, (size_t)1 << 30));
+    const size_t got = gr > 0 ? (size_t)gr : 0;
     if (got == 0) eof = true;
     any_bytes |= got > 0; have += got;
     size_t start = 0;
@@ -152,7 +158,7 @@ int32_t nb_report_tsv(const char* input_path, const char* output_path, double th
     std::memmove(buf.data(), buf.data() + start, have - start); have -= start;
     if (have == buf.size()) buf.resize(buf.size() * 2);
   }
-  std::fclose(in);
+  gzclose(in);
   if (perr == -1 && any_body) { nb::set_error("nb_report_tsv: input TSV lacks nimble_features / nimble_score / r1_CB / r1_UB"); return NB_ERR_INVALID; }
   if (perr == -2) { nb::set_error("nb_report_tsv: non-numeric nimble_score"); return NB_ERR_INVALID; }
   if (!any_bytes || recs.empty()) return write_empty();

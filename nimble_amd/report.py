@@ -57,8 +57,13 @@ def read_rows(path):
     Returns None for "no data", else a list of (cb, umi, features_sorted, score)."""
     if os.path.getsize(path) == 0:
         return None
-    with open(path, newline="") as f:
-        lines = f.read().split("\n")
+    if path.endswith(".gz"):      # pd.read_csv infers gzip from the extension (reference __main__.py:219)
+        import gzip
+        with gzip.open(path, "rt", newline="") as f:
+            lines = f.read().split("\n")
+    else:
+        with open(path, newline="") as f:
+            lines = f.read().split("\n")
     if lines and lines[-1] == "":
         lines.pop()
     lines = [ln[:-1] if ln.endswith("\r") else ln for ln in lines]

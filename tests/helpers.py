@@ -55,3 +55,46 @@ def assert_same(gpu, ora, what=""):
 def library_strings(n_loci, alleles, locus_len=1098, seed=synth.LIB_SEED):
     names, seqs, lineage = synth.synth_library(n_loci, alleles, locus_len, seed)
     return names, seqs, [synth.codes_to_str(s) for s in seqs], lineage
+
+
+# ---- minimal BAM writer (SAM/BAM spec v1.6 §4.2) for tests: BGZF blocks with the BC extra field + EOF block ----
+def _bgzf_block(data):
+    import struct
+    import zlib
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = comp.compress(data) + comp.flush()
+    bsize = len(cdata) + 25
+    head = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize)
+    return head + cdata + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+def write_bam(path, records, refs=(("chr1", 1000),), block=3000):
+    """records: dicts with name, flag, seq, optional qual, tags {tag: str | int}. Unaligned coordinates."""
+    import struct
+    text = b"@HD\tVN:1.6\tSO:unsorted\n"
+    raw = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    for name, ln in refs:
+        nb = name.encode() + b"\x00"
+        raw += struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln)
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    for r in records:
+        name = r["name"].encode() + b"\x00"
+        seq = r["seq"].upper()
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i >> 1] |= code.get(ch, 15) << (0 if i & 1 else 4)
+        qual = bytes(r.get("qual", [30] * len(seq)))
+        tags = b""
+        for t, v in r.get("tags", {}).items():
+            if isinstance(v, int):
+                tags += t.encode() + b"i" + struct.pack("<i", v)
+            elif isinstance(v, (list, tuple)):
+                tags += t.encode() + b"BS" + struct.pack("<i", len(v)) + b"".join(struct.pack("<H", x) for x in v)
+            else:
+                tags += t.encode() + b"Z" + v.encode() + b"\x00"
+        body = struct.pack("<iiBBHHHIiii", -1, -1, len(name), 0, 4680, 0, r["flag"], len(seq), -1, -1, 0) + name + bytes(packed) + qual + tags
+        raw += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as f:
+        for i in range(0, len(raw), block):
+            f.write(_bgzf_block(raw[i:i + block]))
+        f.write(_bgzf_block(b""))

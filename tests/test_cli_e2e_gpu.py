@@ -133,3 +133,69 @@ def test_tenx_per_read_rows_then_report(built, tmp_path):
     got = open(tmp_path / "counts.tsv").read()
     assert got == open(tmp_path / "counts_exp.tsv").read() and len(got.splitlines()) > 5
     assert all(len(l.split("\t")) == 3 for l in got.splitlines())
+
+
+def test_bam_input_single_end_and_pairs(built, tmp_path):
+    """`align --input x.bam`: cellranger-style single-end records with CB/UB tags (some reverse-strand, some without
+    tags) and a name-collated paired uBAM as the reference's fastq-to-bam writes it."""
+    from oracle import oracle
+    from tests.helpers import write_bam
+    lib_path, names, seqs, strs, lineage = make_library(tmp_path, intersect_level=1)
+    rng = np.random.default_rng(8)
+    comp = str.maketrans("ACGTN", "TGCAN")
+    n = 2500
+    codes = synth.synth_reads(seqs, n, 98, seed=12)
+    reads = [synth.codes_to_str(c) for c in codes]
+    recs, cbs, ubs = [], [], []
+    for i, s in enumerate(reads):
+        cb = "" if i % 17 == 0 else "".join("ACGT"[c] for c in rng.integers(0, 4, 16)) + "-1"
+        ub = "".join("ACGT"[c] for c in rng.integers(0, 4, 12))
+        rev = bool(rng.random() < 0.5)
+        tags = {"NH": 1, "UB": ub}
+        if cb:
+            tags["CB"] = cb
+        recs.append({"name": f"r{i}", "flag": 0x10 if rev else 0, "seq": s.translate(comp)[::-1] if rev else s, "tags": tags})
+        if i % 50 == 0:
+            recs.append({"name": f"r{i}", "flag": 0x100, "seq": "ACGTACGT", "tags": {"CB": "zz", "UB": "zz"}})
+        cbs.append(cb); ubs.append(ub)
+    bam = tmp_path / "possorted.bam"
+    write_bam(bam, recs)
+    out = tmp_path / "bam_out.tsv.gz"
+    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(bam)]) == 0
+    lib, ora = expected_bulk(lib_path, reads)
+    want = []
+    for i in range(n):
+        if ora["reason"][i] == 0:
+            feats = lib.feature_list(engine.bits_to_members(ora["set_bits"][i]))
+            want.append("\t".join([",".join(feats), "1", cbs[i], ubs[i]] + [str(x) for x in ora["cov"][i]]))
+    lines = gzip.open(out, "rt").read().split("\n")
+    assert lines[0].split("\t")[:4] == ["nimble_features", "nimble_score", "r1_CB", "r1_UB"] and lines[-1] == ""
+    assert lines[1:-1] == want and len(want) > 1000
+    # report drops the rows without a cell barcode (null r1_CB, __main__.py:244) and counts the rest
+    assert cli(["report", "-i", str(out), "-o", str(tmp_path / "bam_counts.tsv")]) == 0    # .gz input, as pandas infers it
+    from nimble_amd.report import report
+    (tmp_path / "exp.tsv").write_text("\n".join([lines[0]] + want) + "\n")
+    report(str(tmp_path / "exp.tsv"), str(tmp_path / "exp_counts.tsv"), engine="python")
+    got = open(tmp_path / "bam_counts.tsv").read()
+    assert got == open(tmp_path / "exp_counts.tsv").read() and len(got.splitlines()) > 100
+    assert not any(l.endswith("\t") for l in got.splitlines())
+    # name-collated pairs (flags 77 / 141)
+    r1 = [synth.codes_to_str(c) for c in synth.synth_reads(seqs, 800, 90, seed=21)]
+    r2 = [synth.codes_to_str(c) for c in synth.synth_reads(seqs, 800, 75, seed=22)]
+    recs = []
+    for i in range(800):
+        t = {"CB": f"CELL{i % 7}", "UB": f"UMI{i % 90:03d}"}
+        recs += [{"name": f"p{i}", "flag": 77, "seq": r1[i], "tags": t}, {"name": f"p{i}", "flag": 141, "seq": r2[i], "tags": t}]
+    write_bam(tmp_path / "pairs.bam", recs)
+    out2 = tmp_path / "pairs.tsv"
+    assert cli(["align", "--reference", str(lib_path), "--output", str(out2), "--input", str(tmp_path / "pairs.bam")]) == 0
+    c = lib.config
+    cfg = engine.make_config(k=lib.k, score_threshold=c["score_threshold"], score_filter=c["score_filter"], score_percent=c["score_percent"],
+                             intersect_level=c["intersect_level"])
+    ora = oracle.OracleIndex(lib.sequences, lib.k).align_strs(cfg, r1, r2, n_threads=4)
+    want2 = []
+    for i in range(800):
+        if ora["reason"][i] == 0:
+            feats = lib.feature_list(engine.bits_to_members(ora["set_bits"][i]))
+            want2.append("\t".join([",".join(feats), str(ora["mates"][i]), f"CELL{i % 7}", f"UMI{i % 90:03d}"] + [str(x) for x in ora["cov"][i]]))
+    assert open(out2).read().split("\n")[1:-1] == want2 and len(want2) > 300

@@ -157,3 +157,49 @@ def test_native_whitelist_matches_python_rule(built, tmp_path):
     out, ok = nat.correct(cb, cq)
     got = [o.tobytes().decode() if k else None for o, k in zip(out, ok)]
     assert got == want and nat.stats == py.stats and 0 < sum(w is None for w in want) < len(want)
+
+
+def test_bam_reader_single_and_paired(built, tmp_path):
+    from nimble_amd.align import BamReader
+    from tests.helpers import write_bam
+    comp = str.maketrans("ACGTN", "TGCAN")
+    s1, s2, s3 = "ACGTTGCANNACGTAGGCTA" * 3, "TTGACCATGACCAGTNACGT" * 2, "GGGGACGTACGTAAAC"
+    recs = [
+        {"name": "a", "flag": 0, "seq": s1, "tags": {"XX": 7, "CB": "ACGTACGTACGTACGT-1", "BQ": [1, 2, 3], "UB": "AACCGGTTAACC"}},
+        {"name": "sec", "flag": 0x100, "seq": "ACGT", "tags": {"CB": "X"}},                       # secondary: skipped
+        {"name": "b", "flag": 0x10, "seq": s2.translate(comp)[::-1], "tags": {"UB": "TTTT"}},    # stored reverse-complemented, no CB
+        {"name": "c", "flag": 0, "seq": s3},
+    ]
+    p = tmp_path / "se.bam"
+    write_bam(p, recs, block=97)                                                                # many small BGZF members
+    r = BamReader(str(p))
+    b = r.next_batch(2, 100)
+    assert b["n"] == 2 and not b["paired"]
+    want, wl = engine.pack_reads([s1, s2], 100)
+    assert (b["words"] == want).all() and list(b["lens"]) == list(wl)
+    assert b["cb"][0].tobytes().rstrip(b"\x00") == b"ACGTACGTACGTACGT-1" and b["umi"][0].tobytes().rstrip(b"\x00") == b"AACCGGTTAACC"
+    assert b["cb"][1].tobytes().rstrip(b"\x00") == b"" and b["umi"][1].tobytes().rstrip(b"\x00") == b"TTTT"
+    b = r.next_batch(5, 100)
+    assert b["n"] == 1 and (b["words"] == engine.pack_reads([s3], 100)[0]).all()
+    assert r.next_batch(5, 100)["n"] == 0
+    r.close()
+    # pairs: flags 77 / 141 as written by the reference's fastq-to-bam (fastq_barcode_processor.py:185,199)
+    pairs = [{"name": "q1", "flag": 77, "seq": s1, "tags": {"CB": "AAAA", "UB": "CC"}}, {"name": "q1", "flag": 141, "seq": s2, "tags": {"CB": "AAAA", "UB": "CC"}},
+             {"name": "q2", "flag": 141, "seq": s3, "tags": {"CB": "GGGG", "UB": "TT"}}, {"name": "q2", "flag": 77, "seq": s2, "tags": {"CB": "GGGG", "UB": "TT"}}]
+    p2 = tmp_path / "pe.bam"
+    write_bam(p2, pairs)
+    r = BamReader(str(p2))
+    b = r.next_batch(10, 100)
+    assert b["n"] == 2 and b["paired"]
+    assert (b["words"] == engine.pack_reads([s1, s2], 100)[0]).all() and (b["mate_words"] == engine.pack_reads([s2, s3], 100)[0]).all()
+    assert b["cb"][1].tobytes().rstrip(b"\x00") == b"GGGG"
+    r.close()
+    p3 = tmp_path / "bad.bam"
+    write_bam(p3, [pairs[0], pairs[3]])                                                          # mates not adjacent
+    r = BamReader(str(p3))
+    with pytest.raises(engine._lib.NimbleError):
+        r.next_batch(10, 100)
+    r.close()
+    (tmp_path / "not.bam").write_bytes(gzip.compress(b"hello world, not a bam"))
+    with pytest.raises(engine._lib.NimbleError):
+        BamReader(str(tmp_path / "not.bam"))
