@@ -27,7 +27,7 @@ from . import _lib, engine
 from .library import Library
 from .utils import append_path_string, parse_trim
 
-BATCH_READS = 1 << 22
+BATCH_READS = 1 << 20
 MAX_READ_LEN = 339      # NB_MAX_POSITIONS + k - 1 at k = 20
 COV_COLUMNS = ["r1_forward_score", "r1_reverse_score", "r2_forward_score", "r2_reverse_score"]
 
@@ -236,7 +236,10 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         r1 = FastqReader(input[0], num_cores) if not is_bam else None
         r2 = FastqReader(input[1], num_cores) if len(input) == 2 else None
         total, t0 = 0, time.time()
-        while True:
+
+        def fetch():
+            """Next batch of templates from the input files (runs in a helper thread: the C++ readers release the GIL, so
+            parsing batch i+1 overlaps the GPU work and the TSV writing of batch i)."""
             if is_bam:
                 bb = bam.next_batch(min(batch_reads, 1 << 20), MAX_READ_LEN)
                 b1 = {"cb": bb["cb"], "umi": bb["umi"], "cbq": None}
@@ -249,13 +252,22 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
                     raise ValueError("R1 and R2 FASTQ files have different numbers of records")
                 seq, mate = b2, None
             else:
+                b1 = None
                 seq = r1.next_batch(batch_reads, MAX_READ_LEN)
                 mate = r2.next_batch(batch_reads, MAX_READ_LEN) if paired else None
                 if paired and mate["n"] != seq["n"]:
                     raise ValueError("R1 and R2 FASTQ files have different numbers of records")
+            return seq, mate, b1
+
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
+        pending = pool.submit(fetch)
+        while True:
+            seq, mate, b1 = pending.result()
             n = seq["n"]
             if n == 0:
                 break
+            pending = pool.submit(fetch)
             max_len = max(int(seq["lens"].max()), 1)
             stride = engine.packed_stride_words(max_len)
             full = engine.packed_stride_words(MAX_READ_LEN)
@@ -291,6 +303,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         if corrector:
             print(f"cell barcodes: {corrector.stats}")
         print(f"Aligned {total} templates in {time.time() - t0:.2f} s")
+        pool.shutdown(wait=True)
         for rd in (r1, r2, bam):
             if rd:
                 rd.close()
