@@ -988,7 +988,10 @@ __device__ __forceinline__ void combine_mates(bool paired, int reason1, int cov1
   o.reason = reason1 > reason2 ? reason1 : reason2;
 }
 
-template <int NR, int TW>
+// MODE 0: LDS-staged mapper (any num_mismatches, single-end or paired). MODE 1 / 2: exact mode (num_mismatches == 0) with
+// the hot kernel's front ends applied to each mate (1 = one position per lane, 2 = three positions per lane): no staging,
+// both strands of a mate from one pass of lookups — the path of paired FASTQ / paired BAM input.
+template <int NR, int TW, int MODE>
 __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevClasses ct, BatchArgs a) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   __shared__ uint64_t s_seq[4][GEN_WORDS];
@@ -996,7 +999,7 @@ __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevC
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint64_t* seq = s_seq[wave];
+  uint64_t* seq = s_seq[MODE == 0 ? wave : 0];
   const bool paired = a.mates != nullptr;
   const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
   for (long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave; r < a.n; r += nwaves) {
@@ -1010,17 +1013,41 @@ __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevC
       rs[j] = NB_TOO_SHORT; cov[j] = 0;
 #pragma unroll
       for (int t = 0; t < TW; ++t) eq[j][t] = 0;
-      const bool second = j >= 2;
-      if (second && !paired) continue;
-      const int L = second ? L2 : L1;
-      if (L < ix.K) continue;
-      const uint64_t* src = second ? a.mates + (size_t)r * a.mstride : a.reads + (size_t)r * a.stride;
-      const int nwb = second ? a.mnwb : a.nwb;
-      stage_sequence(seq, src, nwb, L, (j & 1) != 0, lane);
-      Strand<NR> S;
-      map_staged<NR>(ix, seq, nwb, L, a.num_mismatches, lane, S);
-      cov[j] = S.cov;
-      rs[j] = evaluate_alignment<NR, TW>(ix, S, L, a, lane, eq[j]);
+    }
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool second = j >= 2;
+        if (second && !paired) continue;
+        const int L = second ? L2 : L1;
+        if (L < ix.K) continue;
+        const uint64_t* src = second ? a.mates + (size_t)r * a.mstride : a.reads + (size_t)r * a.stride;
+        const int nwb = second ? a.mnwb : a.nwb;
+        stage_sequence(seq, src, nwb, L, (j & 1) != 0, lane);
+        Strand<NR> S;
+        map_staged<NR>(ix, seq, nwb, L, a.num_mismatches, lane, S);
+        cov[j] = S.cov;
+        rs[j] = evaluate_alignment<NR, TW>(ix, S, L, a, lane, eq[j]);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (m && !paired) continue;
+        const int L = m ? L2 : L1;
+        if (L < ix.K) continue;
+        const uint64_t* src = m ? a.mates + (size_t)r * a.mstride : a.reads + (size_t)r * a.stride;
+        const int nwb = m ? a.mnwb : a.nwb;
+        Strand<NR> SF, SR;
+        if constexpr (MODE == 2) {
+          const TriRec rec = tri_load_record(src, nwb, L, ix.K, lane);
+          TriProbe q;
+          tri_issue(ix, rec, L, lane, q);
+          tri_finish(ix, q, L, lane, SF, SR);
+        } else map_both_strands_fast<NR>(ix, src, nwb, L, lane, SF, SR);
+        cov[2 * m] = SF.cov; cov[2 * m + 1] = SR.cov;
+        rs[2 * m] = evaluate_alignment<NR, TW>(ix, SF, L, a, lane, eq[2 * m]);
+        rs[2 * m + 1] = evaluate_alignment<NR, TW>(ix, SR, L, a, lane, eq[2 * m + 1]);
+      }
     }
     OrientRes<TW> F, R;
     combine_mates<TW>(paired, rs[0], cov[0], eq[0], rs[3], cov[3], eq[3], a, F);   // F = {map(r1), map(rc(r2))}
@@ -1118,27 +1145,35 @@ static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStrea
   return NB_OK;
 }
 
-template <int NR, int TW>
+// three-positions-per-lane front end: 129..192 positions and k <= 29 (window of k+3 bases in one 64-bit word)
+static bool use_tri(int positions, int k) { return positions > 128 && positions <= 192 && k <= 29; }
+
+template <int NR, int TW, int MODE>
 static int launch_general(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
-  const long long blocks = resident_blocks(c, nb_align_general_kernel<NR, TW>, a.n);
-  hipLaunchKernelGGL((nb_align_general_kernel<NR, TW>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
+  const long long blocks = resident_blocks(c, nb_align_general_kernel<NR, TW, MODE>, a.n);
+  hipLaunchKernelGGL((nb_align_general_kernel<NR, TW, MODE>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
 
 template <int TW>
-static int dispatch_general(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
+static int dispatch_general(nb_ctx* c, int nr, int positions, bool exact, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
+  if (exact && use_tri(positions, ix.K)) return launch_general<3, TW, 2>(c, ix, a, s);
+  if (exact) switch (nr) {
+    case 1: return launch_general<1, TW, 1>(c, ix, a, s);
+    case 2: return launch_general<2, TW, 1>(c, ix, a, s);
+    case 3: return launch_general<3, TW, 1>(c, ix, a, s);
+    case 4: return launch_general<4, TW, 1>(c, ix, a, s);
+    default: return launch_general<5, TW, 1>(c, ix, a, s);
+  }
   switch (nr) {
-    case 1: return launch_general<1, TW>(c, ix, a, s);
-    case 2: return launch_general<2, TW>(c, ix, a, s);
-    case 3: return launch_general<3, TW>(c, ix, a, s);
-    case 4: return launch_general<4, TW>(c, ix, a, s);
-    default: return launch_general<5, TW>(c, ix, a, s);
+    case 1: return launch_general<1, TW, 0>(c, ix, a, s);
+    case 2: return launch_general<2, TW, 0>(c, ix, a, s);
+    case 3: return launch_general<3, TW, 0>(c, ix, a, s);
+    case 4: return launch_general<4, TW, 0>(c, ix, a, s);
+    default: return launch_general<5, TW, 0>(c, ix, a, s);
   }
 }
-
-// three-positions-per-lane front end: 129..192 positions and k <= 29 (window of k+3 bases in one 64-bit word)
-static bool use_tri(int positions, int k) { return positions > 128 && positions <= 192 && k <= 29; }
 
 template <int TW>
 static int dispatch_se(nb_ctx* c, int nr, int positions, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
@@ -1300,7 +1335,8 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   a.require_valid_pair = cfg->require_valid_pair; a.strand_filter = cfg->strand_filter;
   const int nr = positions < 1 ? 1 : (positions + 63) / 64;
   if (d_mates || cfg->num_mismatches > 0)   // pairs and tolerated mismatches take the general (eager, LDS-staged) kernel
-    return (c->W <= 64) ? dispatch_general<1>(c, nr, ix, a, s) : dispatch_general<4>(c, nr, ix, a, s);
+    return (c->W <= 64) ? dispatch_general<1>(c, nr, positions, cfg->num_mismatches == 0, ix, a, s)
+                        : dispatch_general<4>(c, nr, positions, cfg->num_mismatches == 0, ix, a, s);
   return (c->W <= 64) ? dispatch_se<1>(c, nr, positions, ix, a, s) : dispatch_se<4>(c, nr, positions, ix, a, s);
 }
 
@@ -1348,7 +1384,7 @@ int32_t nb_counts_device_ptr(nb_ctx* c, void** d_counts, int64_t* capacity) {
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired) {
   static thread_local char buf[96];
   const int positions = max_len - k + 1; const int nr = positions < 1 ? 1 : (positions + 63) / 64; const int W = (n_seqs + 63) / 64;
-  if (paired) std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d>", nr > 5 ? 5 : nr, W <= 64 ? 1 : 4);
+  if (paired) std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d, %d>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? 2 : 1);
   else std::snprintf(buf, sizeof buf, "nb_align_se_kernel<%d, %d, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? "true" : "false");
   return buf;
 }

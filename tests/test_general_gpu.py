@@ -113,3 +113,13 @@ def test_dictionary_agreement_ops_on_gpu(built):
     dense = torch.zeros(g_gpu.shape[0], dtype=torch.int64, device="cuda")
     dense.index_add_(0, i_gpu[:5000], torch.ones(5000, dtype=torch.int64, device="cuda"))
     assert int(dense.sum()) == 5000 and int(dense.max()) == 1
+
+
+@pytest.mark.parametrize("l1,l2,kw", [(150, 140, dict(intersect_level=1)), (150, 60, dict()), (100, 150, dict(intersect_level=2, require_valid_pair=True)),
+                                      (211, 250, dict(intersect_level=1))])
+def test_pairs_exact_mode_front_ends(built, l1, l2, kw):
+    """Exact-mode paired path: three-per-lane front end when the longer mate has 129..192 positions, one-per-lane otherwise."""
+    _, seqs, strs, _ = library_strings(4, 8, locus_len=700, seed=41)
+    c1, c2 = synth_pairs(seqs, 2500, l1, l2, seed=9, frag=320 if max(l1, l2) < 300 else 400)
+    gpu, ora = _both(strs, engine.make_config(**kw), c1, c2)
+    assert_same(gpu, ora, f"pairs exact {l1}/{l2} {kw}")
