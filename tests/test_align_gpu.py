@@ -123,3 +123,38 @@ def test_determinism_and_batches(built):
     got = {r.tobytes(): int(c) for r, c in zip(rows, counts)}
     want = {r.tobytes(): int(c) for r, c in zip(a["rows"], a["counts"])}
     assert got == want
+
+
+def test_class_table_overflow_is_loud(built):
+    """More distinct result sets than max_classes: no silent loss — reading the classes raises NB_ERR_OVERFLOW."""
+    import torch
+    _, seqs, strs, _ = library_strings(20, 50)
+    codes = synth.synth_reads(seqs, 60000, 150, seed=23)
+    index = engine.Index(strs, 20)
+    ctx = engine.Context(0, max_classes=64)
+    ctx.upload(index)
+    d = torch.from_numpy(synth.pack_codes(codes).view(np.int64)).cuda()
+    ctx.align_batch(engine.make_config(), d, None, 150, n=codes.shape[0])
+    ctx.sync()
+    with pytest.raises(engine._lib.NimbleError) as e:
+        ctx.classes()
+    assert e.value.code == -4
+    ctx.reset(); ctx.sync()
+    rows, counts = ctx.classes()
+    assert rows.shape[0] == 0
+
+
+def test_many_classes_under_contention(built):
+    """Tens of thousands of distinct sets interned concurrently by thousands of waves into a tight table (load ~0.5):
+    ids must be unique per set and counts exact."""
+    _, seqs, strs, _ = library_strings(20, 50)
+    codes = synth.synth_reads(seqs, 400000, 150, seed=29, err=0.03)
+    index = engine.Index(strs, 20)
+    words = synth.pack_codes(codes)
+    gpu = run_gpu(index, engine.make_config(), words, None, 150, max_classes=1 << 15)
+    keys = [r.tobytes() for r in gpu["rows"]]
+    assert len(set(keys)) == len(keys) > 12000                       # every set interned exactly once
+    called = gpu["class"] != engine.NO_CLASS
+    assert int(gpu["counts"].sum()) == int(called.sum()) == int(gpu["reasons"][0])
+    assert (np.bincount(gpu["class"][called], minlength=len(keys)) == gpu["counts"]).all()
+    assert (gpu["rows"] != 0).any(axis=1).all()
