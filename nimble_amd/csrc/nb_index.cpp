@@ -111,8 +111,8 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
   const uint32_t n_col = (uint32_t)(col_off.size() - 1);
   if (n_col > MAX_COLOURS) { set_error("nb_index_build: more than 2^22-1 equivalence classes"); return NB_ERR_UNSUPPORTED; }
 
-  // 3. final colour ids: ascending set size, ties by member list (lexicographic). The kernels rely on
-  //    "smaller id = no larger set" to seed the intersection with the smallest class without a size lookup.
+  // 3. final colour ids: ascending set size, ties by member list (lexicographic): a canonical numbering that depends on
+  //    the library only (not on k-mer encoding or hash order).
   std::vector<uint32_t> order(n_col); std::iota(order.begin(), order.end(), 0u);
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
     const uint64_t la = col_off[a + 1] - col_off[a], lb = col_off[b + 1] - col_off[b];

@@ -2,7 +2,8 @@
 //
 // Replaces the per-read work of the Rust `nimble-aligner` binary spawned at /root/reference/nimble/__main__.py:195
 // (k-mer extraction, index lookup, equivalence-class intersection, scoring, filtering, counting). Semantics:
-// docs/SPEC.md. Formulation: ONE READ PER WAVE, ONE K-MER POSITION PER LANE.
+// docs/SPEC.md. Formulation: ONE READ PER WAVE, ONE K-MER POSITION PER LANE (three consecutive positions
+// per lane for reads with 129..192 positions).
 //   1. every lane extracts its k-mer from the 2-bit packed read, canonicalises it and reads its 32-byte home bucket of
 //      the canonical-k-mer table; the slot carries the payload of BOTH strands, so one lookup serves read and reverse
 //      complement;
@@ -10,9 +11,9 @@
 //   3. the SPEC §3 walk (stride-3 seeding, left extension, runs, re-seeding) becomes a handful of find-first-bit
 //      operations on those masks, executed uniformly by the wave (the reverse strand is walked downwards over the same
 //      read-position order, no mask reversal);
-//   4. the colours of the visited positions are intersected: the smallest class row seeds an accumulator spread
-//      over the lanes (one u64 word per lane), then for each non-zero word every visited lane gathers its own
-//      class's word and a wave AND-reduction folds them;
+//   4. the colours of the visited positions are intersected from their 32-byte span descriptors: the common word
+//      window is the intersection of the spans (two wave reductions), and per word of that window a wave AND-reduction
+//      folds the lanes' class words (one memory round trip for classes that live inside one locus);
 //   5. the result set is interned in a lock-free class table (64-bit content hash + full compare) and counted.
 // Integer/bit work only: no MFMA. Wave = 64 everywhere.
 #include <hip/hip_runtime.h>
