@@ -172,6 +172,12 @@ int32_t nb_format_tenx_rows(int64_t n, const uint32_t* cls, const uint32_t* info
  * number of UMIs dropped for an empty intersection. ---- */
 int32_t nb_report_tsv(const char* input_path, const char* output_path, double threshold, int32_t disable_thresholding,
                       int64_t* status_out);
+/* the same reduction from arrays, skipping the per-read TSV: row i = (cb_strings[cb_ids[i]], umi_keys[i] (any key that
+ * identifies the UMI), feat_strings[feat_ids[i]] (features sorted and comma-joined), scores[i]); rows need not be
+ * merged or ordered; empty cb / feature strings mark null rows. Same output text as nb_report_tsv on the equivalent TSV. */
+int32_t nb_report_rows(int64_t n, const uint32_t* cb_ids, const uint64_t* umi_keys, const uint32_t* feat_ids, const int64_t* scores,
+                       int64_t n_cb, const char* const* cb_strings, int64_t n_feat, const char* const* feat_strings, double threshold,
+                       int32_t disable_thresholding, const char* output_path, int64_t* status_out);
 
 /* name of the kernel nb_align_batch launches for this shape (for matching rocprofv3 kernel-trace rows) */
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired);

@@ -35,6 +35,9 @@ def build_parser():
     a.add_argument("--cb-length", help="Length of cell barcode (default: 16).", type=int, default=16)
     a.add_argument("--umi-length", help="Length of UMI (default: 12).", type=int, default=12)
     a.add_argument("--device", help="GPU index (default 0).", type=int, default=0)
+    a.add_argument("--report-output", help="Also write the per-cell counts `report` would produce from the per-read table (barcoded input only).", type=str, default=None)
+    a.add_argument("--report-threshold", help="Threshold of the fused report (default: 0.05).", type=float, default=0.05)
+    a.add_argument("--report-disable-thresholding", help="Disable thresholding in the fused report.", action="store_true", default=False)
 
     r = sub.add_parser("report")
     r.add_argument("-i", "--input", help="The input file.", type=str, required=True)
@@ -63,7 +66,8 @@ def main(argv=None):
     if args.subcommand == "align":
         tenx = TenxOptions(args.map, args.cb_length, args.umi_length) if args.tenx else None
         return align(args.reference, args.output, args.input, args.num_cores, args.strand_filter, args.trim, args.tmpdir,
-                     tenx=tenx, device_id=args.device)
+                     tenx=tenx, device_id=args.device, report_output=args.report_output, report_threshold=args.report_threshold,
+                     report_disable_thresholding=args.report_disable_thresholding)
     if args.subcommand == "report":
         cols = args.summarize.split(",") if args.summarize else None
         report(args.input, args.output, cols, args.threshold, args.disable_thresholding)

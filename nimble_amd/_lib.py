@@ -59,6 +59,8 @@ SIGNATURES = {
     "nb_counts_device_ptr": (ct.c_int32, [ct.c_void_p, ct.POINTER(ct.c_void_p), c_i64p]),
     "nb_kernel_name": (ct.c_char_p, [ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32]),
     "nb_report_tsv": (ct.c_int32, [ct.c_char_p, ct.c_char_p, ct.c_double, ct.c_int32, c_i64p]),
+    "nb_report_rows": (ct.c_int32, [ct.c_int64, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int64, ct.POINTER(ct.c_char_p),
+                                    ct.c_int64, ct.POINTER(ct.c_char_p), ct.c_double, ct.c_int32, ct.c_char_p, c_i64p]),
     "nb_fastq_open": (ct.c_int32, [ct.c_char_p, ct.POINTER(ct.c_void_p)]),
     "nb_fastq_close": (ct.c_int32, [ct.c_void_p]),
     "nb_fastq_set_threads": (ct.c_int32, [ct.c_void_p, ct.c_int32]),

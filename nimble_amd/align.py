@@ -23,7 +23,7 @@ import time
 
 import numpy as np
 
-from . import _lib, engine
+from . import _lib, engine, fused
 from .library import Library
 from .utils import append_path_string, parse_trim
 
@@ -117,6 +117,9 @@ class LibraryRun:
         self.per_read = per_read
         self.class_feature = []     # class id -> feature string, or None when a class-level filter rejects it
         self.class_reason = []
+        self.class_feat_id = []     # class id -> index into feat_strings (sorted, comma-joined features), -1 if rejected
+        self.feat_index, self.feat_strings = {}, []
+        self.rows = None            # fused per-cell counting (RowAccumulator), when requested
         self.bulk = {}
         self.n_rows = 0
         self.fh = None
@@ -136,6 +139,13 @@ class LibraryRun:
                 reason = 11   # NB_MULTI_HITS
             self.class_feature.append(",".join(feats) if reason == 0 else None)
             self.class_reason.append(reason)
+            fid = -1
+            if reason == 0:
+                key = ",".join(sorted(feats))          # report sorts the features of a row (__main__.py:248)
+                fid = self.feat_index.setdefault(key, len(self.feat_strings))
+                if fid == len(self.feat_strings):
+                    self.feat_strings.append(key)
+            self.class_feat_id.append(fid)
         return rows, counts
 
     def finish(self):
@@ -197,12 +207,25 @@ def _write_per_read(run, cls, info_raw, cov_raw, cb, cb_ok, umi):
                                               umi.shape[1], buf.ctypes.data, cap, ct.byref(out_len), ct.byref(n_rows)))
     run.fh.write(buf[:out_len.value].tobytes())
     run.n_rows += n_rows.value
+    if run.rows is not None:       # the same rows, as arrays, for the fused per-cell counting
+        cfid = np.asarray(run.class_feat_id, dtype=np.int64)
+        ok = ((info_raw >> 16) & 0xFF) == 0
+        ok &= cls != engine.NO_CLASS
+        fid = np.full(n, -1, dtype=np.int64)
+        fid[ok] = cfid[cls[ok]]
+        ok &= fid >= 0
+        if cb_ok is not None:
+            ok &= cb_ok != 0
+        ok &= (cb.view(np.uint8).reshape(n, -1)[:, 0] != 0) & (umi.view(np.uint8).reshape(n, -1)[:, 0] != 0)   # null CB / UB rows
+        if ok.any():
+            run.rows.add(run.rows.cb_ids_of(cb[ok]), run.rows.umi_keys_of(umi[ok]), fid[ok], ((info_raw[ok] >> 25) & 3).astype(np.int64))
 
 
 def align(reference, output, input, num_cores=1, strand_filter="unstranded", trim="", tmpdir=None, tenx=None, device_id=0,
-          batch_reads=BATCH_READS):
-    """Same positional arguments and return value as the reference's align() (__main__.py:153). `tenx`, `device_id`
-    and `batch_reads` are extensions with neutral defaults."""
+          batch_reads=BATCH_READS, report_output=None, report_threshold=0.05, report_disable_thresholding=False):
+    """Same positional arguments and return value as the reference's align() (__main__.py:153). `tenx`, `device_id`,
+    `batch_reads` and `report_output` (fused per-cell counting: also write what `report` would produce from the per-read
+    table, without re-reading it; one file per library, named like the outputs) are extensions with neutral defaults."""
     try:
         import torch
         print("Aligning input data to the reference libraries")
@@ -229,6 +252,11 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         for lib in libs:
             suffix = "." + os.path.splitext(os.path.basename(lib))[0] if len(libs) > 1 else ""
             runs.append(LibraryRun(lib, append_path_string(output, suffix), strand_filter, device_id, per_read))
+            if report_output:
+                if not per_read:
+                    raise ValueError("report_output needs barcoded input (BAM or --tenx)")
+                runs[-1].rows = fused.RowAccumulator()
+                runs[-1].report_path = append_path_string(report_output, suffix)
         corrector = None
         if tenx is not None and tenx.whitelist:
             corrector = NativeWhitelist(tenx.whitelist)
@@ -297,6 +325,9 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
             total += n
         for run in runs:
             run.finish()
+            if run.rows is not None:
+                nrows = run.rows.finish(None, run.feat_strings, run.report_path, report_threshold, report_disable_thresholding)
+                print(f"{run.lib.stem}: per-cell counts from {nrows} merged rows -> {run.report_path}")
             reasons = run.ctx.reasons()
             print(f"{run.lib.stem}: {total} templates, {int(reasons[0])} called, {run.n_rows} output rows -> {run.out_path}")
             print("  reasons: " + ", ".join(f"{engine.REASONS[i]}={int(v)}" for i, v in enumerate(reasons) if v))

@@ -151,6 +151,25 @@ def report_native(input, output, threshold=0.05, disable_thresholding=False):
         print(f"Dropped {st[1]} UMIs due to empty intersections")
 
 
+def report_rows(cb_ids, umi_keys, feat_ids, scores, cb_strings, feat_strings, output, threshold=0.05, disable_thresholding=False):
+    """report() from arrays instead of a per-read TSV (nb_report_rows): row i = (cb_strings[cb_ids[i]], umi_keys[i],
+    feat_strings[feat_ids[i]], scores[i]). Same output text as report() on the equivalent TSV."""
+    import ctypes as ct
+    from . import _lib
+    cb_ids = np.ascontiguousarray(cb_ids, dtype=np.uint32); umi_keys = np.ascontiguousarray(umi_keys, dtype=np.uint64)
+    feat_ids = np.ascontiguousarray(feat_ids, dtype=np.uint32); scores = np.ascontiguousarray(scores, dtype=np.int64)
+    n = cb_ids.shape[0]
+    cbs = (ct.c_char_p * max(1, len(cb_strings)))(*[s.encode() if isinstance(s, str) else s for s in cb_strings])
+    fts = (ct.c_char_p * max(1, len(feat_strings)))(*[s.encode() if isinstance(s, str) else s for s in feat_strings])
+    st = (ct.c_int64 * 2)()
+    _lib.check(_lib.lib().nb_report_rows(n, cb_ids.ctypes.data, umi_keys.ctypes.data, feat_ids.ctypes.data, scores.ctypes.data, len(cb_strings), cbs,
+                                         len(feat_strings), fts, float(threshold), int(bool(disable_thresholding)), os.fsencode(output), st))
+    if st[0]:
+        print("No data to parse from input file, writing empty output.")
+    else:
+        print(f"Dropped {st[1]} UMIs due to empty intersections")
+
+
 def report(input, output, summarize_columns_list=None, threshold=0.05, disable_thresholding=False, engine=None):
     """Same signature and output as the reference's report() (__main__.py:254). `engine`: "python" (this module) or
     "native" (nb_report_tsv); default from $NIMBLE_REPORT_ENGINE, else native. Both are pinned by the same fixtures."""

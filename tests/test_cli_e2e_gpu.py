@@ -111,7 +111,8 @@ def test_tenx_per_read_rows_then_report(built, tmp_path):
     write_fastq(tmp_path / "R2.fastq.gz", [f"q{i}/2" for i in range(n)], r2)
     out = tmp_path / "per_read.tsv"
     assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(tmp_path / "R1.fastq.gz"),
-                str(tmp_path / "R2.fastq.gz"), "--tenx", "--map", str(tmp_path / "wl.txt")]) == 0
+                str(tmp_path / "R2.fastq.gz"), "--tenx", "--map", str(tmp_path / "wl.txt"), "--report-output", str(tmp_path / "fused.tsv"),
+                "--report-threshold", "0.1"]) == 0
     lib, ora = expected_bulk(lib_path, r2)
     from nimble_amd import barcodes
     corr = barcodes.BarcodeCorrector(set(wl))
@@ -133,6 +134,9 @@ def test_tenx_per_read_rows_then_report(built, tmp_path):
     got = open(tmp_path / "counts.tsv").read()
     assert got == open(tmp_path / "counts_exp.tsv").read() and len(got.splitlines()) > 5
     assert all(len(l.split("\t")) == 3 for l in got.splitlines())
+    # fused per-cell counting (no TSV round trip) == report on the TSV, same threshold
+    report(str(out), str(tmp_path / "counts_01.tsv"), threshold=0.1, engine="python")
+    assert open(tmp_path / "fused.tsv").read() == open(tmp_path / "counts_01.tsv").read()
 
 
 def test_bam_input_single_end_and_pairs(built, tmp_path):
@@ -161,7 +165,7 @@ def test_bam_input_single_end_and_pairs(built, tmp_path):
     bam = tmp_path / "possorted.bam"
     write_bam(bam, recs)
     out = tmp_path / "bam_out.tsv.gz"
-    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(bam)]) == 0
+    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(bam), "--report-output", str(tmp_path / "bam_fused.tsv")]) == 0
     lib, ora = expected_bulk(lib_path, reads)
     want = []
     for i in range(n):
@@ -179,6 +183,7 @@ def test_bam_input_single_end_and_pairs(built, tmp_path):
     got = open(tmp_path / "bam_counts.tsv").read()
     assert got == open(tmp_path / "exp_counts.tsv").read() and len(got.splitlines()) > 100
     assert not any(l.endswith("\t") for l in got.splitlines())
+    assert open(tmp_path / "bam_fused.tsv").read() == got          # fused path, incl. the rows without CB dropped
     # name-collated pairs (flags 77 / 141)
     r1 = [synth.codes_to_str(c) for c in synth.synth_reads(seqs, 800, 90, seed=21)]
     r2 = [synth.codes_to_str(c) for c in synth.synth_reads(seqs, 800, 75, seed=22)]

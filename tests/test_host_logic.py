@@ -203,3 +203,30 @@ def test_bam_reader_single_and_paired(built, tmp_path):
     (tmp_path / "not.bam").write_bytes(gzip.compress(b"hello world, not a bam"))
     with pytest.raises(engine._lib.NimbleError):
         BamReader(str(tmp_path / "not.bam"))
+
+
+def test_fused_row_accumulator_equals_report_on_tsv(built, tmp_path):
+    """merge_rows + nb_report_rows (the fused per-cell counting) == report() on the per-read TSV, incl. N-containing UMIs,
+    several batches and duplicate rows."""
+    from nimble_amd import fused, report as rep
+    rng = np.random.default_rng(17)
+    feats = ["A*01", "A*01,A*02", "B*07", "A*02,B*07,C*04", "C*04"]
+    cells = ["".join("ACGT"[c] for c in rng.integers(0, 4, 16)) for _ in range(12)]
+    umis = ["".join("ACGTN"[c] for c in rng.integers(0, 5, 12)) for _ in range(400)]
+    n = 6000
+    ci, ui, fi = rng.integers(0, 12, n), rng.integers(0, 400, n), rng.integers(0, 5, n)
+    mates = rng.integers(1, 3, n)
+    tsv = tmp_path / "in.tsv"
+    with open(tsv, "w") as f:
+        f.write("nimble_features\tnimble_score\tr1_CB\tr1_UB\n")
+        for i in range(n):
+            f.write(f"{feats[fi[i]]}\t{mates[i]}\t{cells[ci[i]]}\t{umis[ui[i]]}\n")
+    rep.report(str(tsv), str(tmp_path / "want.tsv"), threshold=0.2, engine="python")
+    acc = fused.RowAccumulator()
+    cb_arr = np.array([list(cells[c]) for c in ci], dtype="S1"); umi_arr = np.array([list(umis[u]) for u in ui], dtype="S1")
+    for lo in range(0, n, 2500):
+        sl = slice(lo, lo + 2500)
+        acc.add(acc.cb_ids_of(cb_arr[sl]), acc.umi_keys_of(umi_arr[sl]), fi[sl], mates[sl])
+    merged = acc.finish(None, feats, str(tmp_path / "got.tsv"), threshold=0.2)
+    assert merged < n and open(tmp_path / "got.tsv").read() == open(tmp_path / "want.tsv").read()
+    assert fused.decode_umi(fused.encode_umis(umi_arr[:1])[0], 12) == umis[ui[0]]

@@ -33,3 +33,23 @@ def test_pinned_survey_vector(tmp_path):
     for engine in ("python", "native"):
         rep.report(str(i), str(o), engine=engine)
         assert o.read_text() == "A\t1\tcell1\nB,D\t1\tcell1\nG\t1\tcell3\n"
+
+
+@pytest.mark.parametrize("idx", range(0, len(CASES), 3))
+def test_report_rows_equals_report_on_tsv(idx, tmp_path, built):
+    """Array entry point (nb_report_rows, used by the fused per-cell counting) == the TSV path on the golden inputs with
+    integer scores."""
+    c = CASES[idx]
+    lines = [l for l in c["input"].split("\n")[1:] if l]
+    header = c["input"].split("\n")[0].split("\t")
+    if isinstance(c["output"], dict) or not lines or header[:4] != list(rep.REQUIRED):
+        pytest.skip("no plain-integer table in this case")
+    rows = [l.split("\t") for l in lines]
+    if any(len(r) < 4 or any(v in rep._NA for v in r[:4]) or not r[1].lstrip("-").isdigit() for r in rows):
+        pytest.skip("float scores / null fields: TSV-only semantics")
+    cbs, fts, umis = sorted({r[2] for r in rows}), sorted({",".join(sorted(r[0].split(","))) for r in rows}), sorted({r[3] for r in rows})
+    cb_ids = [cbs.index(r[2]) for r in rows]; ft_ids = [fts.index(",".join(sorted(r[0].split(",")))) for r in rows]
+    umi_keys = [1000 - umis.index(r[3]) for r in rows]                      # any injective key, deliberately not order preserving
+    o = tmp_path / "o.tsv"
+    rep.report_rows(cb_ids, umi_keys, ft_ids, [int(r[1]) for r in rows], cbs, fts, str(o), c["threshold"], c["disable_thresholding"])
+    assert o.read_text() == c["output"]
