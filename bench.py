@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=20_000)
+    ap.add_argument("--per-cell", action="store_true",
+                    help="c3 only, after the timed region: synthetic cell/UMI ids per read, merge the per-read calls on the GPU and run the "
+                         "report reduction (fused per-cell counting); reported under 'per_cell', not part of 'value'")
     ap.add_argument("--backend", default=os.environ.get("NB_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 logic on a 1-GPU box)")
     args = ap.parse_args()
@@ -184,6 +187,53 @@ def main():
         if (t.get("reads_per_gpu"), t.get("read_len"), t.get("n_seqs"), t.get("k")) == (n, L, len(strs), args.k) and "traffic_bytes_per_launch" in t:
             traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.basename(f)
 
+    # ---- optional: per-cell counts for the 10x workload (BASELINE configs[2] asks for them), outside the timed region ----
+    per_cell = None
+    if args.per_cell and world == 1:
+        from nimble_amd import fused
+        import tempfile
+        t0 = time.perf_counter()
+        g = torch.Generator(device=dev); g.manual_seed(33)
+        n_cells = 10_000                                                  # 10 000 cells, a few reads per UMI
+        # reads of one UMI come from one molecule, i.e. share their call: derive the molecule id from the read's class
+        umi_id = (out_class.to(torch.int64) & 0xFFFFFFFF) * 64 + torch.randint(0, 64, (n,), generator=g, device=dev)
+        cb_ids = (umi_id * 2654435761) % n_cells                          # a UMI belongs to one cell
+        umi_codes = (umi_id * 40503) % (1 << 24)                          # 12-base UMI = 24 bits
+        # class -> feature string id on the host (names of the members; classes with > 10 features are rejected: max_hits_to_report)
+        bits = np.unpackbits(rows.view(np.uint8), axis=1, bitorder="little")
+        sizes = bits.sum(axis=1)
+        keep = np.nonzero((sizes > 0) & (sizes <= 10))[0]
+        ci, mi = np.nonzero(bits[keep])
+        feat_strings, cfid = [], np.full(rows.shape[0], -1, dtype=np.int64)
+        starts = np.searchsorted(ci, np.arange(keep.shape[0] + 1))
+        index_of = {}
+        for j, c in enumerate(keep):
+            key = ",".join(sorted(names[m] for m in mi[starts[j]:starts[j + 1]]))
+            fid = index_of.setdefault(key, len(feat_strings))
+            if fid == len(feat_strings):
+                feat_strings.append(key)
+            cfid[c] = fid
+        t_map = time.perf_counter() - t0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        cls_t = out_class.to(torch.int64) & 0xFFFFFFFF
+        called = cls_t != engine.NO_CLASS
+        fid_t = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        fid_t[called] = torch.from_numpy(cfid).to(dev)[cls_t[called]]
+        ok = fid_t >= 0
+        merged = fused.merge_rows(cb_ids[ok], umi_codes[ok], fid_t[ok], torch.ones(int(ok.sum()), dtype=torch.int64, device=dev))
+        cols = [m.cpu().numpy() for m in merged]
+        torch.cuda.synchronize(); t_merge = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with tempfile.TemporaryDirectory() as d:
+            outp = os.path.join(d, "per_cell.tsv")
+            from nimble_amd.report import report_rows
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):               # stdout carries exactly one JSON line
+                report_rows(cols[0], cols[1], cols[2], cols[3], [f"CELL{i:05d}" for i in range(n_cells)], feat_strings, outp)
+            n_out = sum(1 for _ in open(outp))
+        per_cell = {"reads": int(n), "called_rows": int(ok.sum()), "merged_rows": int(cols[0].shape[0]), "class_to_feature_s": t_map,
+                    "gpu_merge_s": t_merge, "reduce_s": time.perf_counter() - t0, "output_rows": n_out, "cells": n_cells}
+
     line = {
         "metric": "M reads/s aligned (150bp, 1k-seq HLA lib)" if args.config == "c2" else f"M reads/s aligned ({args.config})", "value": value, "unit": "M reads/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -199,6 +249,7 @@ def main():
         "parity_sample_ok": parity,
         "index": {"kmers": stats["n_kmers"], "colours": stats["n_colours"], "table_MB": stats["table_slots"] * 16 / 1e6,
                   "device_MB": stats["device_bytes"] / 1e6, "build_s": t_index},
+        "per_cell": per_cell,
         "classes": int(glob_rows.shape[0]), "called_frac": float(reasons[0] / max(1, reasons.sum())), "readgen_s": t_gen,
     }
     print(json.dumps(line))
