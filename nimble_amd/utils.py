@@ -17,7 +17,8 @@ def append_path_string(input_path, path_append_string):
 
 def parse_trim(trim, n_libraries):
     """--trim "<TARGET_LENGTH>:<STRICTNESS>,..." one entry per library (/root/reference/nimble/__main__.py:400).
-    Validated and returned; trimming itself is the identity (docs/SPEC.md §5, as the reference's own stub utils.py:116)."""
+    Validated and returned; reads are not trimmed: the rule lives in the external aligner and is specified nowhere in the
+    reference tree (docs/SPEC.md §5, open item)."""
     if trim == "" or trim is None:
         return None
     parts = trim.split(",")
