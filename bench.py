@@ -177,7 +177,7 @@ def main():
 
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
     # from the committed rocprofv3 PMC passes of the SAME workload (scripts/profile_gpu.sh -> profiles/*_traffic.json).
-    traffic, traffic_src = None, None
+    traffic, traffic_src, miss_requests = None, None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
@@ -186,6 +186,7 @@ def main():
             continue
         if (t.get("reads_per_gpu"), t.get("read_len"), t.get("n_seqs"), t.get("k")) == (n, L, len(strs), args.k) and "traffic_bytes_per_launch" in t:
             traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.basename(f)
+            miss_requests = t.get("TCC_MISS_sum")
 
     # ---- optional: per-cell counts for the 10x workload (BASELINE configs[2] asks for them), outside the timed region ----
     per_cell = None
@@ -245,6 +246,11 @@ def main():
                                       "Infinity Cache; algorithmic bytes per launch = " + str(bytes_per_read * n)) if traffic else None,
                      "kernel": engine._lib.lib().nb_kernel_name(L, args.k, len(strs), 0).decode(), "kernel_ms_avg": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_read": bytes_per_read},
+        # The ceiling this kernel actually runs into (profiles/r01_tuning_notes.md): the rate at which L2-miss requests
+        # (64 B each, TCC_MISS_sum of the committed PMC pass) can be served by the fabric / Infinity Cache / HBM, measured
+        # at 55-57 G requests/s on this chip (two-choice cuckoo experiment on c2; c5, whose index lives in HBM, sits there).
+        "secondary_roofline": ({"bound": "l2_miss_requests", "achieved": miss_requests / avg_kernel_s / 1e9, "peak": 56.0, "unit": "G requests/s",
+                                "frac": miss_requests / avg_kernel_s / 1e9 / 56.0, "misses_per_read": miss_requests / n} if miss_requests else None),
         "cpu_baseline": cpu,
         "parity_sample_ok": parity,
         "index": {"kmers": stats["n_kmers"], "colours": stats["n_colours"], "table_MB": stats["table_slots"] * 16 / 1e6,
