@@ -136,6 +136,17 @@ int32_t nb_fastq_close(nb_fastq* fq);
 int32_t nb_fastq_set_threads(nb_fastq* fq, int32_t threads);
 int32_t nb_fastq_next_batch(nb_fastq* fq, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
                             int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len, char* cbqual_out);
+/* the same in two steps, so that the caller can size the packed layout to the batch: index finds the next records and
+ * reports the longest sequence line; pack writes them (max_len >= that length) and consumes the batch. */
+int32_t nb_fastq_index_batch(nb_fastq* fq, int64_t max_reads, int64_t* n_out, int32_t* max_seq_len_out);
+int32_t nb_fastq_pack_batch(nb_fastq* fq, int32_t max_len, uint64_t* out_words, uint16_t* out_lens, char* cb_out, int32_t cb_len,
+                            char* umi_out, int32_t umi_len, char* cbqual_out);
+/* streaming form used by align.py: cache-sized sub-batches, all packed at the layout of *max_len_out = the longest read
+ * of the first sub-batch (the batch ends early before a longer read); out_words holds max_reads *
+ * nb_packed_stride_words(cap_len) words, cap_len = longest read accepted. */
+int32_t nb_fastq_next_batch_tight(nb_fastq* fq, int64_t max_reads, int32_t cap_len, uint64_t* out_words, uint16_t* out_lens,
+                                  int64_t* n_out, int32_t* max_len_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len,
+                                  char* cbqual_out);
 
 /* ---- BAM input (host, zlib only): replaces the Rust binary's BAM decode for `--input x.bam` (__main__.py:171-175).
  * No sort is needed (the reference sorts by UR only so that its aligner sees one UMI's records together,

@@ -39,32 +39,54 @@ class TenxOptions:
         self.whitelist, self.cb_length, self.umi_length = whitelist, int(cb_length), int(umi_length)
 
 
+def _host_buffer(shape, dtype, pinned):
+    """numpy array for reader output; page-locked (through torch) when a GPU is there, so that the H2D copy is a plain DMA.
+    Allocated once per reader and reused: first touch of fresh pages costs more than parsing into them."""
+    if pinned:
+        import torch
+        t = torch.empty(int(np.prod(shape)) * np.dtype(dtype).itemsize, dtype=torch.uint8, pin_memory=True)
+        return t.numpy().view(dtype).reshape(shape)
+    return np.empty(shape, dtype=dtype)
+
+
 class FastqReader:
-    def __init__(self, path, threads=1):
+    """nb_fastq_* (csrc/nb_ingest.cpp). Batches alternate between two buffer sets: a returned batch stays valid until the
+    second next_batch() call after it (align() parses batch i+1 while batch i is on the GPU)."""
+
+    def __init__(self, path, threads=1, pinned=False):
         self._h = ct.c_void_p()
         _lib.check(_lib.lib().nb_fastq_open(path.encode(), ct.byref(self._h)))
         _lib.check(_lib.lib().nb_fastq_set_threads(self._h, int(threads)))
+        self._pinned = pinned
+        self._sets, self._turn = {}, 0
+
+    def _buffers(self, kind, max_reads, shape_tail, dtype):
+        key = (kind, self._turn & 1)
+        buf = self._sets.get(key)
+        if buf is None or buf.shape[0] < max_reads or buf.shape[1:] != tuple(shape_tail):
+            buf = self._sets[key] = _host_buffer((max_reads,) + tuple(shape_tail), dtype, self._pinned)
+        return buf
 
     def next_batch(self, max_reads, max_len=None, barcodes_only=False, cb_len=0, umi_len=0):
-        """Returns dict(n, words, lens, cb, umi, cbq)."""
-        n = ct.c_int64()
-        out = {}
+        """Returns dict(n, words, lens, max_len, cb, umi, cbq). The reads are packed at the layout of the batch's own longest
+        read (`max_len` in the result); the argument `max_len` is the longest read accepted."""
+        n, batch_len = ct.c_int64(), ct.c_int32()
+        L = _lib.lib()
+        self._turn += 1
         if barcodes_only:
-            cb = np.zeros((max_reads, cb_len), dtype="S1")
-            umi = np.zeros((max_reads, umi_len), dtype="S1")
-            cbq = np.zeros((max_reads, cb_len), dtype="S1")
-            _lib.check(_lib.lib().nb_fastq_next_batch(self._h, max_reads, 1, None, None, ct.byref(n), cb.ctypes.data, cb_len,
-                                                      umi.ctypes.data, umi_len, cbq.ctypes.data))
-            out.update(cb=cb[:n.value], umi=umi[:n.value], cbq=cbq[:n.value])
-        else:
-            stride = engine.packed_stride_words(max_len)
-            words = np.zeros((max_reads, stride), dtype=np.uint64)
-            lens = np.zeros(max_reads, dtype=np.uint16)
-            _lib.check(_lib.lib().nb_fastq_next_batch(self._h, max_reads, max_len, words.ctypes.data, lens.ctypes.data, ct.byref(n),
-                                                      None, 0, None, 0, None))
-            out.update(words=words[:n.value], lens=lens[:n.value])
-        out["n"] = n.value
-        return out
+            cb = self._buffers("cb", max_reads, (cb_len,), "S1")
+            umi = self._buffers("umi", max_reads, (umi_len,), "S1")
+            cbq = self._buffers("cbq", max_reads, (cb_len,), "S1")
+            _lib.check(L.nb_fastq_next_batch_tight(self._h, max_reads, 1, None, None, ct.byref(n), ct.byref(batch_len), cb.ctypes.data, cb_len,
+                                                   umi.ctypes.data, umi_len, cbq.ctypes.data))
+            k = n.value
+            return {"n": k, "cb": cb[:k], "umi": umi[:k], "cbq": cbq[:k]}
+        flat = self._buffers("words", max_reads, (engine.packed_stride_words(max_len),), np.uint64).reshape(-1)
+        lens = self._buffers("lens", max_reads, (), np.uint16)
+        _lib.check(L.nb_fastq_next_batch_tight(self._h, max_reads, max_len, flat.ctypes.data, lens.ctypes.data, ct.byref(n), ct.byref(batch_len),
+                                               None, 0, None, 0, None))
+        k, stride = n.value, engine.packed_stride_words(max(batch_len.value, 1))
+        return {"n": k, "words": flat[:k * stride].reshape(k, stride), "lens": lens[:k], "max_len": max(batch_len.value, 1)}
 
     def close(self):
         if self._h:
@@ -123,6 +145,8 @@ class LibraryRun:
         self.bulk = {}
         self.n_rows = 0
         self.fh = None
+        self._snap = None
+        self._row_buf = None
         if per_read:
             self.fh = gzip.open(out_path, "wb", compresslevel=4) if out_path.endswith(".gz") else open(out_path, "wb")
             self.fh.write(("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n").encode())
@@ -147,6 +171,17 @@ class LibraryRun:
                     self.feat_strings.append(key)
             self.class_feat_id.append(fid)
         return rows, counts
+
+    def snapshot(self):
+        """(ctypes array of class feature strings, its length, longest string, class -> feature-string id) for the classes
+        known now; rebuilt only when classes were added. Call with the GPU idle (reads the class table)."""
+        self.refresh_classes()
+        feats = self.class_feature
+        if self._snap is None or self._snap[1] != len(feats):
+            arr = (ct.c_char_p * max(1, len(feats)))(*[f.encode() if f is not None else None for f in feats])
+            self._snap = (arr, len(feats), max((len(f) for f in feats if f is not None), default=0),
+                          np.asarray(self.class_feat_id, dtype=np.int64))
+        return self._snap
 
     def finish(self):
         if self.per_read:
@@ -189,26 +224,23 @@ class NativeWhitelist:
             self._h = None
 
 
-def _write_per_read(run, cls, info_raw, cov_raw, cb, cb_ok, umi):
-    """Format this batch's rows in C++ (nb_format_tenx_rows) and append them to the run's TSV."""
-    run.refresh_classes()
+def _write_per_read(run, snap, cls, info_raw, cov_raw, cb, cb_ok, umi):
+    """Format this batch's rows in C++ (nb_format_tenx_rows) and append them to the run's TSV. `snap` = the run's class ->
+    feature tables as of this batch (LibraryRun.snapshot(), taken on the main thread while the GPU was idle)."""
+    feat_arr, n_feats, feat_max, cfid = snap
     n = cls.shape[0]
-    feats = run.class_feature
-    if len(feats) != getattr(run, "_feat_n", -1):
-        run._feat_arr = (ct.c_char_p * max(1, len(feats)))(*[f.encode() if f is not None else None for f in feats])
-        run._feat_n = len(feats)
-        run._feat_max = max((len(f) for f in feats if f is not None), default=0)
     cb, umi = np.ascontiguousarray(cb), np.ascontiguousarray(umi)
-    cap = n * (run._feat_max + cb.shape[1] + umi.shape[1] + 64) + 64
-    buf = np.empty(cap, dtype=np.uint8)
+    cap = n * (feat_max + cb.shape[1] + umi.shape[1] + 64) + 64
+    if run._row_buf is None or run._row_buf.shape[0] < cap:
+        run._row_buf = np.empty(cap, dtype=np.uint8)
+    buf = run._row_buf
     out_len, n_rows = ct.c_int64(), ct.c_int64()
-    _lib.check(_lib.lib().nb_format_tenx_rows(n, cls.ctypes.data, info_raw.ctypes.data, cov_raw.ctypes.data, run._feat_arr, len(feats),
+    _lib.check(_lib.lib().nb_format_tenx_rows(n, cls.ctypes.data, info_raw.ctypes.data, cov_raw.ctypes.data, feat_arr, n_feats,
                                               cb.ctypes.data, cb.shape[1], cb_ok.ctypes.data if cb_ok is not None else None, umi.ctypes.data,
                                               umi.shape[1], buf.ctypes.data, cap, ct.byref(out_len), ct.byref(n_rows)))
-    run.fh.write(buf[:out_len.value].tobytes())
+    run.fh.write(memoryview(buf[:out_len.value]))
     run.n_rows += n_rows.value
     if run.rows is not None:       # the same rows, as arrays, for the fused per-cell counting
-        cfid = np.asarray(run.class_feat_id, dtype=np.int64)
         ok = ((info_raw >> 16) & 0xFF) == 0
         ok &= cls != engine.NO_CLASS
         fid = np.full(n, -1, dtype=np.int64)
@@ -261,13 +293,15 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         if tenx is not None and tenx.whitelist:
             corrector = NativeWhitelist(tenx.whitelist)
         bam = BamReader(input[0]) if is_bam else None
-        r1 = FastqReader(input[0], num_cores) if not is_bam else None
-        r2 = FastqReader(input[1], num_cores) if len(input) == 2 else None
+        r1 = FastqReader(input[0], num_cores, pinned=True) if not is_bam else None
+        r2 = FastqReader(input[1], num_cores, pinned=True) if len(input) == 2 else None
         total, t0 = 0, time.time()
+        prof = _StageClock()
 
         def fetch():
-            """Next batch of templates from the input files (runs in a helper thread: the C++ readers release the GIL, so
-            parsing batch i+1 overlaps the GPU work and the TSV writing of batch i)."""
+            """Next batch of templates from the input files, barcodes corrected (runs in a helper thread: the C++ readers
+            release the GIL, so parsing batch i+1 overlaps the GPU work and the TSV writing of batch i)."""
+            t = time.perf_counter()
             if is_bam:
                 bb = bam.next_batch(min(batch_reads, 1 << 20), MAX_READ_LEN)
                 b1 = {"cb": bb["cb"], "umi": bb["umi"], "cbq": None}
@@ -275,54 +309,76 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
                 mate = {"n": bb["n"], "words": bb["mate_words"], "lens": bb["mate_lens"]} if bb["paired"] else None
             elif per_read:
                 b1 = r1.next_batch(batch_reads, barcodes_only=True, cb_len=tenx.cb_length, umi_len=tenx.umi_length)
-                b2 = r2.next_batch(batch_reads, MAX_READ_LEN)
-                if b1["n"] != b2["n"]:
-                    raise ValueError("R1 and R2 FASTQ files have different numbers of records")
-                seq, mate = b2, None
+                seq, mate = r2.next_batch(b1["n"], MAX_READ_LEN) if b1["n"] else {"n": 0}, None
+                if seq["n"] != b1["n"]:
+                    seq = _top_up(r2, seq, b1["n"])
             else:
                 b1 = None
                 seq = r1.next_batch(batch_reads, MAX_READ_LEN)
-                mate = r2.next_batch(batch_reads, MAX_READ_LEN) if paired else None
-                if paired and mate["n"] != seq["n"]:
-                    raise ValueError("R1 and R2 FASTQ files have different numbers of records")
+                mate = r2.next_batch(seq["n"], MAX_READ_LEN) if paired and seq["n"] else None
+                if paired and seq["n"] and mate["n"] != seq["n"]:
+                    mate = _top_up(r2, mate, seq["n"])
+            if (per_read or paired) and seq["n"] == 0 and not is_bam and r2.next_batch(1, MAX_READ_LEN)["n"]:
+                raise ValueError("R1 and R2 FASTQ files have different numbers of records")
+            if per_read and seq["n"]:
+                b1["cb_fixed"], b1["cb_ok"] = corrector.correct(b1["cb"], b1["cbq"]) if corrector else (b1["cb"], None)
+            prof.add("ingest (helper thread)", time.perf_counter() - t)
             return seq, mate, b1
 
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1)
+        writer = ThreadPoolExecutor(max_workers=1)
+        write_jobs = []
         pending = pool.submit(fetch)
+        host_out = [None, None]          # two sets of pinned result buffers: the writer thread reads one while the GPU fills the other
+        turn = 0
         while True:
-            seq, mate, b1 = pending.result()
+            with prof("wait for input"):
+                seq, mate, b1 = pending.result()
             n = seq["n"]
             if n == 0:
                 break
             pending = pool.submit(fetch)
-            max_len = max(int(seq["lens"].max()), 1)
-            stride = engine.packed_stride_words(max_len)
-            full = engine.packed_stride_words(MAX_READ_LEN)
-            words = _repack(seq["words"], MAX_READ_LEN, max_len) if stride != full else seq["words"]
-            d_reads = torch.from_numpy(words.view(np.int64)).to(dev)
-            d_lens = torch.from_numpy(seq["lens"].view(np.int16)).to(dev)
-            d_mates = d_mlens = None
-            mmax = 0
-            if mate is not None:
-                mmax = max(int(mate["lens"].max()), 1)
-                mw = _repack(mate["words"], MAX_READ_LEN, mmax) if engine.packed_stride_words(mmax) != full else mate["words"]
-                d_mates = torch.from_numpy(mw.view(np.int64)).to(dev)
-                d_mlens = torch.from_numpy(mate["lens"].view(np.int16)).to(dev)
-            out_class = torch.empty(n, dtype=torch.int32, device=dev)
-            out_info = torch.empty(n, dtype=torch.int32, device=dev)
-            out_cov = torch.empty(n, dtype=torch.int64, device=dev) if per_read else None
-            cbs = cb_ok = None
-            if per_read:
-                cbs, cb_ok = corrector.correct(b1["cb"], b1["cbq"]) if corrector else (b1["cb"], None)
+            with prof("H2D"):
+                words, max_len = _tight(seq)
+                d_reads = torch.from_numpy(words.view(np.int64)).to(dev, non_blocking=True)
+                d_lens = torch.from_numpy(seq["lens"].view(np.int16)).to(dev, non_blocking=True)
+                d_mates = d_mlens = None
+                mmax = 0
+                if mate is not None:
+                    mw, mmax = _tight(mate)
+                    d_mates = torch.from_numpy(mw.view(np.int64)).to(dev, non_blocking=True)
+                    d_mlens = torch.from_numpy(mate["lens"].view(np.int16)).to(dev, non_blocking=True)
+                out_class = torch.empty(n, dtype=torch.int32, device=dev)
+                out_info = torch.empty(n, dtype=torch.int32, device=dev)
+                out_cov = torch.empty(n, dtype=torch.int64, device=dev) if per_read else None
             for run in runs:
-                run.ctx.align_batch(run.cfg, d_reads, d_lens, max_len, out_class, out_info, out_cov, mates=d_mates, mate_lens=d_mlens,
-                                    mate_max_len=mmax, n=n)
-                run.ctx.sync()
+                with prof("align kernel + sync"):
+                    run.ctx.align_batch(run.cfg, d_reads, d_lens, max_len, out_class, out_info, out_cov, mates=d_mates, mate_lens=d_mlens,
+                                        mate_max_len=mmax, n=n)
+                    run.ctx.sync()
                 if per_read:
-                    _write_per_read(run, out_class.cpu().numpy().view(np.uint32), out_info.cpu().numpy().view(np.uint32),
-                                    out_cov.cpu().numpy().view(np.uint64), cbs, cb_ok, b1["umi"])
+                    with prof("wait for writer"):
+                        while len(write_jobs) >= 2:
+                            write_jobs.pop(0).result()
+                    with prof("D2H"):
+                        if host_out[turn] is None or host_out[turn][0].shape[0] < n:
+                            cap = max(n, batch_reads)
+                            host_out[turn] = (torch.empty(cap, dtype=torch.int32, pin_memory=True), torch.empty(cap, dtype=torch.int32, pin_memory=True),
+                                              torch.empty(cap, dtype=torch.int64, pin_memory=True))
+                        h_class, h_info, h_cov = (t[:n] for t in host_out[turn])
+                        h_class.copy_(out_class); h_info.copy_(out_info); h_cov.copy_(out_cov)
+                        turn ^= 1
+                    with prof("class snapshot"):
+                        snap = run.snapshot()
+                    write_jobs.append(writer.submit(_timed, prof, "TSV rows (writer thread)", _write_per_read, run, snap, h_class.numpy().view(np.uint32),
+                                                    h_info.numpy().view(np.uint32), h_cov.numpy().view(np.uint64), b1["cb_fixed"], b1["cb_ok"],
+                                                    b1["umi"] if is_bam else b1["umi"].copy()))   # (reader buffers are recycled two batches on)
             total += n
+        with prof("wait for writer"):
+            for j in write_jobs:
+                j.result()
+        writer.shutdown(wait=True)
         for run in runs:
             run.finish()
             if run.rows is not None:
@@ -334,6 +390,8 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         if corrector:
             print(f"cell barcodes: {corrector.stats}")
         print(f"Aligned {total} templates in {time.time() - t0:.2f} s")
+        if os.environ.get("NB_PROFILE"):
+            print("  stages: " + prof.report())
         pool.shutdown(wait=True)
         for rd in (r1, r2, bam):
             if rd:
@@ -345,10 +403,70 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         return 1
 
 
+def _timed(prof, name, fn, *args):
+    t = time.perf_counter()
+    try:
+        return fn(*args)
+    finally:
+        prof.add(name, time.perf_counter() - t)
+
+
+class _StageClock:
+    """Wall time per pipeline stage; printed at the end of align() when NB_PROFILE is set."""
+
+    def __init__(self):
+        self.t = {}
+
+    def add(self, name, dt):
+        self.t[name] = self.t.get(name, 0.0) + dt
+
+    def __call__(self, name):
+        clock = self
+
+        class _Span:
+            def __enter__(self):
+                self.t0 = time.perf_counter()
+
+            def __exit__(self, *exc):
+                clock.add(name, time.perf_counter() - self.t0)
+        return _Span()
+
+    def report(self):
+        return ", ".join(f"{k} {v:.2f} s" for k, v in self.t.items())
+
+
+def _top_up(reader, batch, want):
+    """A reader may end a batch early (longer read ahead, csrc/nb_ingest.cpp); mates must stay aligned with their partners, so
+    fetch the rest and concatenate (rare: copies)."""
+    parts = [{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()}]
+    have = batch["n"]
+    while have < want:
+        more = reader.next_batch(want - have, MAX_READ_LEN)
+        if more["n"] == 0:
+            raise ValueError("R1 and R2 FASTQ files have different numbers of records")
+        parts.append({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in more.items()})
+        have += more["n"]
+    max_len = max(p["max_len"] for p in parts)
+    words = np.concatenate([p["words"] if p["max_len"] == max_len else _repack(p["words"], p["max_len"], max_len) for p in parts])
+    return {"n": have, "words": words, "lens": np.concatenate([p["lens"] for p in parts]), "max_len": max_len}
+
+
+def _tight(batch):
+    """(words, max_len) of a reader batch at the layout of its own longest read. FASTQ batches arrive that way; BAM batches are
+    packed at MAX_READ_LEN and re-strided here."""
+    if "max_len" in batch:
+        return batch["words"], batch["max_len"]
+    max_len = max(int(batch["lens"].max()), 1)
+    if engine.packed_stride_words(max_len) == batch["words"].shape[1]:
+        return batch["words"], max_len
+    return _repack(batch["words"], MAX_READ_LEN, max_len), max_len
+
+
 def _repack(words, from_len, to_len):
-    """Re-stride packed reads from layout(max_len=from_len) to layout(max_len=to_len <= from_len)."""
-    nwb_f, nwb_t, nwn_t = (from_len + 31) // 32, (to_len + 31) // 32, (to_len + 63) // 64
-    out = np.empty((words.shape[0], nwb_t + nwn_t), dtype=np.uint64)
-    out[:, :nwb_t] = words[:, :nwb_t]
-    out[:, nwb_t:] = words[:, nwb_f:nwb_f + nwn_t]
+    """Re-stride packed reads from layout(max_len=from_len) to layout(max_len=to_len); no read may be longer than to_len."""
+    nwb_f, nwn_f, nwb_t, nwn_t = (from_len + 31) // 32, (from_len + 63) // 64, (to_len + 31) // 32, (to_len + 63) // 64
+    out = np.zeros((words.shape[0], nwb_t + nwn_t), dtype=np.uint64)
+    nb, nn = min(nwb_f, nwb_t), min(nwn_f, nwn_t)
+    out[:, :nb] = words[:, :nb]
+    out[:, nwb_t:nwb_t + nn] = words[:, nwb_f:nwb_f + nn]
     return out

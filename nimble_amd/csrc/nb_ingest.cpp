@@ -3,50 +3,174 @@
 // Replaces the FASTQ decode the Rust binary performs on each "--input" file (/root/reference/nimble/__main__.py:177-179)
 // and, for 10x data, the barcode/UMI split of R1 that the reference does in Python
 // (/root/reference/nimble/fastq_barcode_processor.py:131-141: CB = r1[:cb_len], UMI = r1[cb_len:cb_len+umi_len]).
-// zlib's gzopen reads plain and gzip files alike. One thread inflates/reads and indexes record boundaries (memchr);
-// `threads` workers (the reference's -c/--num_cores, __main__.py:398) then pack the sequences in parallel.
+//
+// Three stages, sized so that the host keeps up with the GPU for as long as the storage format allows:
+//   1. a background thread per file reads (plain: read(2); gzip: zlib inflate, inherently serial per stream) into
+//      chunks, ahead of the consumer, so R1 and R2 inflate concurrently and overlap packing, the GPU and the writer;
+//   2. record boundaries: `threads` workers (the reference's -c/--num_cores, __main__.py:398) find the newlines of the
+//      buffered text in parallel; strict 4-line framing is verified per record ('@' and '+' lines) and any anomaly
+//      (blank lines between records, truncation) falls back to the serial line walker, which also words the errors;
+//   3. the same workers pack the sequence lines 32 bases per word through a lookup table.
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "nb_internal.h"
 
+namespace {
+
+constexpr size_t CHUNK_BYTES = (size_t)8 << 20;
+constexpr size_t MAX_QUEUED_CHUNKS = 16;
+
+struct Chunk { char* p = nullptr; size_t n = 0; };
+
+struct CodeTable {
+  uint8_t t[256];
+  CodeTable() {
+    std::memset(t, 4, sizeof t);   // 4 = invalid (N): base bits 0, mask bit 1
+    t[(int)'A'] = t[(int)'a'] = 0; t[(int)'C'] = t[(int)'c'] = 1; t[(int)'G'] = t[(int)'g'] = 2; t[(int)'T'] = t[(int)'t'] = 3;
+  }
+};
+const CodeTable CODES;
+
+// device layout of one read (nb_packed_stride_words): nwb words of 2-bit bases, then ceil(max_len/64) words of N mask
+inline void pack_one(const char* b, int64_t L, int nwb, int64_t stride, uint64_t* w) {
+  const uint8_t* s = (const uint8_t*)b;
+  int64_t j = 0; int word = 0;
+  for (; word < nwb && j < L; ++word) {
+    const int64_t m = std::min<int64_t>(32, L - j);
+    uint64_t bits = 0, nm = 0;
+    for (int64_t u = 0; u < m; ++u) {
+      const uint64_t c = CODES.t[s[j + u]];
+      bits |= (c & 3) << (2 * u);
+      nm |= (c >> 2) << u;
+    }
+    w[word] = bits;
+    if (word & 1) w[nwb + (word >> 1)] |= nm << 32; else w[nwb + (word >> 1)] = nm;
+    j += m;
+  }
+  for (int z = word; z < nwb; ++z) w[z] = 0;
+  for (int64_t z = nwb + ((word + 1) >> 1); z < stride; ++z) w[z] = 0;
+}
+
+template <class F>
+void parallel_for(int T, F&& f) {
+  if (T <= 1) { f(0); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)T - 1);
+  for (int t = 1; t < T; ++t) th.emplace_back([&f, t] { f(t); });
+  f(0);
+  for (auto& x : th) x.join();
+}
+
+}  // namespace
+
 struct nb_fastq {
-  gzFile f = nullptr;
-  std::vector<char> buf;      // raw text; [pos, end) is unconsumed
-  size_t pos = 0, end = 0;
+  // source + read-ahead thread
+  int fd = -1;
+  gzFile gz = nullptr;
+  std::thread reader;
+  std::mutex mu;
+  std::condition_variable cv_data, cv_space;
+  std::deque<Chunk> chunks;
+  std::vector<char*> spare;      // recycled chunk buffers (first touch of fresh pages is the expensive part of a chunk)
+  bool src_done = false, stop = false;
+  std::string src_error;
+  // text of the current batch; [pos, end) is unconsumed. malloc-managed (no zero fill on growth)
+  char* buf = nullptr;
+  size_t cap = 0, pos = 0, end = 0, next_pos = 0;   // next_pos: where the indexed batch ends (pos moves there when it is packed)
   bool eof = false;
   int64_t record = 0;
   int threads = 1;
-  std::vector<size_t> seq_b, seq_e, qual_b, qual_e;   // per record of the current batch: offsets into buf
+  // index of the current batch: offsets into buf
+  std::vector<size_t> nl;
+  std::vector<size_t> seq_b, seq_e, qual_b, qual_e;
+  int64_t n_indexed = 0;
+  int32_t longest = 0;
+  bool indexed = false;
+
+  void read_loop() {
+    for (;;) {
+      Chunk c;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!spare.empty()) { c.p = spare.back(); spare.pop_back(); }
+      }
+      if (!c.p) c.p = (char*)std::malloc(CHUNK_BYTES);
+      std::string err;
+      if (!c.p) err = "out of memory";
+      while (c.p && c.n < CHUNK_BYTES) {
+        long got;
+        if (gz) {
+          got = gzread(gz, c.p + c.n, (unsigned)(CHUNK_BYTES - c.n));
+          if (got < 0) { int e = 0; const char* m = gzerror(gz, &e); err = std::string("gzip stream error: ") + (m ? m : "?"); break; }
+        } else {
+          got = (long)::read(fd, c.p + c.n, CHUNK_BYTES - c.n);
+          if (got < 0) { err = "read error"; break; }
+        }
+        if (got == 0) break;
+        c.n += (size_t)got;
+      }
+      std::unique_lock<std::mutex> lk(mu);
+      if (!err.empty()) { src_error = err; src_done = true; std::free(c.p); cv_data.notify_all(); return; }
+      const bool last = c.n < CHUNK_BYTES;
+      if (c.n) chunks.push_back(c); else std::free(c.p);
+      if (last) src_done = true;
+      cv_data.notify_all();
+      if (last) return;
+      cv_space.wait(lk, [&] { return stop || chunks.size() < MAX_QUEUED_CHUNKS; });
+      if (stop) return;
+    }
+  }
+
+  // append the next chunk to buf; false at end of data (or on a source error: see src_error)
+  bool fill() {
+    if (eof) return false;
+    Chunk c;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_data.wait(lk, [&] { return !chunks.empty() || src_done; });
+      if (chunks.empty()) { eof = true; return false; }
+      c = chunks.front(); chunks.pop_front();
+      cv_space.notify_all();
+    }
+    if (end + c.n > cap) {
+      size_t ncap = std::max<size_t>(cap * 2, end + c.n);
+      char* nb_ = (char*)std::realloc(buf, ncap);
+      if (!nb_) { std::free(c.p); src_error = "out of memory"; eof = true; return false; }
+      buf = nb_; cap = ncap;
+    }
+    std::memcpy(buf + end, c.p, c.n);
+    end += c.n;
+    { std::lock_guard<std::mutex> lk(mu); spare.push_back(c.p); }
+    return true;
+  }
 };
 
 namespace {
 
-bool fill(nb_fastq* q) {   // append more bytes; the buffer may grow (callers keep OFFSETS, never pointers)
-  if (q->eof) return false;
-  if (q->end == q->buf.size()) q->buf.resize(q->buf.size() * 2);
-  const int got = gzread(q->f, q->buf.data() + q->end, (unsigned)std::min<size_t>(q->buf.size() - q->end, (size_t)1 << 30));
-  if (got <= 0) { q->eof = true; return false; }
-  q->end += (size_t)got; return true;
-}
-
 // next line [*b, *e) as OFFSETS into buf (without \n / \r), scanning from *cursor; advances *cursor. 0 at end of data.
 int next_line(nb_fastq* q, size_t* cursor, size_t* b, size_t* e) {
   for (;;) {
-    const char* base = q->buf.data();
-    const char* nl = (const char*)std::memchr(base + *cursor, '\n', q->end - *cursor);
+    const char* base = q->buf;
+    const char* nl = *cursor < q->end ? (const char*)std::memchr(base + *cursor, '\n', q->end - *cursor) : nullptr;
     if (nl) {
       *b = *cursor; *e = (size_t)(nl - base);
       *cursor = *e + 1;
       if (*e > *b && base[*e - 1] == '\r') --*e;
       return 1;
     }
-    if (!fill(q)) {
+    if (!q->fill()) {
       if (*cursor < q->end) {  // last line without newline
         *b = *cursor; *e = q->end; *cursor = q->end;
         if (*e > *b && q->buf[*e - 1] == '\r') --*e;
@@ -57,49 +181,10 @@ int next_line(nb_fastq* q, size_t* cursor, size_t* b, size_t* e) {
   }
 }
 
-inline void pack_one(const char* b, int64_t L, int nwb, int64_t stride, uint64_t* w) {
-  std::memset(w, 0, (size_t)stride * 8);
-  for (int64_t j = 0; j < L; ++j) {
-    uint64_t c;
-    switch (b[j]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break;
-      default: c = 0; w[nwb + (j >> 6)] |= 1ull << (j & 63); }
-    w[j >> 5] |= c << ((j & 31) * 2);
-  }
-}
-
-}  // namespace
-
-extern "C" {
-
-int32_t nb_fastq_open(const char* path, nb_fastq** out) {
-  if (!path || !out) { nb::set_error("nb_fastq_open: null argument"); return NB_ERR_INVALID; }
-  gzFile f = gzopen(path, "rb");
-  if (!f) { nb::set_error(std::string("nb_fastq_open: cannot open ") + path); return NB_ERR_INVALID; }
-  gzbuffer(f, 1 << 20);
-  nb_fastq* q = new nb_fastq(); q->f = f; q->buf.resize((size_t)1 << 24);
-  *out = q; return NB_OK;
-}
-
-int32_t nb_fastq_close(nb_fastq* q) { if (q) { if (q->f) gzclose(q->f); delete q; } return NB_OK; }
-
-int32_t nb_fastq_set_threads(nb_fastq* q, int32_t threads) {
-  if (!q) { nb::set_error("nb_fastq_set_threads: null handle"); return NB_ERR_INVALID; }
-  q->threads = threads < 1 ? 1 : (threads > 256 ? 256 : threads); return NB_OK;
-}
-
-// Reads up to max_reads records; *n_out = records read (0 = end of file).
-//   out_words != NULL: the whole sequence line is packed at stride nb_packed_stride_words(max_len), length to out_lens.
-//   cb_out / umi_out != NULL: bases [0, cb_len) and [cb_len, cb_len + umi_len) of the sequence line are copied, fixed
-//   width, to cb_out[i * cb_len] / umi_out[i * umi_len] (the 10x R1 layout); cbqual_out != NULL additionally receives
-//   the quality characters of the CB bases (for the lowest-quality tie-break of the whitelist correction).
-int32_t nb_fastq_next_batch(nb_fastq* q, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
-                            int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len, char* cbqual_out) {
-  if (!q || !n_out || max_reads < 0) { nb::set_error("nb_fastq_next_batch: bad arguments"); return NB_ERR_INVALID; }
-  // compact: drop consumed bytes so the offsets recorded below stay valid while the buffer grows
-  if (q->pos > 0) { std::memmove(q->buf.data(), q->buf.data() + q->pos, q->end - q->pos); q->end -= q->pos; q->pos = 0; }
+// serial indexer: tolerates blank lines between records and words the parse errors
+int32_t index_serial(nb_fastq* q, int64_t max_reads) {
   q->seq_b.clear(); q->seq_e.clear(); q->qual_b.clear(); q->qual_e.clear();
   size_t cur = 0; int64_t n = 0;
-  // phase 1 (serial): read / inflate and index record boundaries
   while (n < max_reads) {
     size_t b, e;
     if (!next_line(q, &cur, &b, &e)) break;
@@ -112,13 +197,153 @@ int32_t nb_fastq_next_batch(nb_fastq* q, int64_t max_reads, int32_t max_len, uin
     q->seq_b.push_back(sb); q->seq_e.push_back(se); q->qual_b.push_back(qb); q->qual_e.push_back(qe);
     ++n;
   }
-  q->pos = cur;
-  // phase 2 (parallel): validate + pack
-  const int nwb = (max_len + 31) / 32; const int64_t stride = nb_packed_stride_words(max_len);
-  const char* base = q->buf.data();
+  q->next_pos = cur; q->n_indexed = n;
+  return NB_OK;
+}
+
+// parallel newline scan of buf[from, to): appends the offsets of '\n' to q->nl in order
+void scan_newlines(nb_fastq* q, size_t from, size_t to) {
+  if (to <= from) return;
+  const int T = (int)std::min<size_t>((size_t)q->threads, std::max<size_t>(1, (to - from) >> 20));
+  std::vector<std::vector<size_t>> part((size_t)T);
+  const char* base = q->buf;
+  parallel_for(T, [&](int t) {
+    const size_t lo = from + (to - from) * (size_t)t / (size_t)T, hi = from + (to - from) * (size_t)(t + 1) / (size_t)T;
+    auto& v = part[(size_t)t];
+    v.reserve((hi - lo) / 64 + 16);
+    const char* p = base + lo; const char* e = base + hi;
+    while (p < e) {
+      const char* x = (const char*)std::memchr(p, '\n', (size_t)(e - p));
+      if (!x) break;
+      v.push_back((size_t)(x - base));
+      p = x + 1;
+    }
+  });
+  size_t total = q->nl.size();
+  for (auto& v : part) total += v.size();
+  q->nl.reserve(total);
+  for (auto& v : part) q->nl.insert(q->nl.end(), v.begin(), v.end());
+}
+
+// fast indexer: strict 4-line records. Returns 1 when it indexed the batch, 0 when the serial walker must take over.
+int index_fast(nb_fastq* q, int64_t max_reads) {
+  const size_t want = (size_t)max_reads * 4;
+  q->nl.clear();
+  size_t scanned = 0;
+  bool virtual_nl = false;
+  for (;;) {
+    scan_newlines(q, scanned, q->end);
+    scanned = q->end;
+    if (q->nl.size() >= want) break;
+    if (!q->fill()) {
+      if (q->end > 0 && q->buf[q->end - 1] != '\n') { q->nl.push_back(q->end); virtual_nl = true; }   // last line without newline
+      break;
+    }
+  }
+  const int64_t n = (int64_t)std::min<size_t>((size_t)max_reads, q->nl.size() / 4);
+  if (n == 0) return q->end == 0 ? 1 : 0;   // nothing left at all, or a tail the serial walker must judge
+  q->seq_b.resize((size_t)n); q->seq_e.resize((size_t)n); q->qual_b.resize((size_t)n); q->qual_e.resize((size_t)n);
+  const int T = (int)std::min<int64_t>(q->threads, std::max<int64_t>(1, n / 4096));
+  std::vector<int> bad((size_t)T, 0);
+  const char* base = q->buf; const size_t* nl = q->nl.data();
+  parallel_for(T, [&](int t) {
+    const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+    for (int64_t i = lo; i < hi; ++i) {
+      const size_t h = i ? nl[4 * i - 1] + 1 : 0;
+      const size_t sb = nl[4 * i] + 1, pb = nl[4 * i + 1] + 1, qb = nl[4 * i + 2] + 1;
+      size_t se = nl[4 * i + 1], qe = nl[4 * i + 3];
+      if (base[h] != '@' || nl[4 * i] == h || base[pb] != '+') { bad[(size_t)t] = 1; return; }
+      if (se > sb && base[se - 1] == '\r') --se;
+      if (qe > qb && base[qe - 1] == '\r') --qe;
+      q->seq_b[(size_t)i] = sb; q->seq_e[(size_t)i] = se; q->qual_b[(size_t)i] = qb; q->qual_e[(size_t)i] = qe;
+    }
+  });
+  for (int b : bad) if (b) return 0;
+  q->next_pos = std::min(q->end, nl[4 * n - 1] + 1);
+  (void)virtual_nl;
+  q->n_indexed = n;
+  return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t nb_fastq_open(const char* path, nb_fastq** out) {
+  if (!path || !out) { nb::set_error("nb_fastq_open: null argument"); return NB_ERR_INVALID; }
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) { nb::set_error(std::string("nb_fastq_open: cannot open ") + path); return NB_ERR_INVALID; }
+  unsigned char magic[2] = {0, 0};
+  const long got = (long)::read(fd, magic, 2);
+  ::lseek(fd, 0, SEEK_SET);
+  nb_fastq* q = new nb_fastq();
+  if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+    q->gz = gzdopen(fd, "rb");
+    if (!q->gz) { ::close(fd); delete q; nb::set_error(std::string("nb_fastq_open: cannot open ") + path); return NB_ERR_INVALID; }
+    gzbuffer(q->gz, 1 << 20);
+  } else {
+    q->fd = fd;
+  }
+  q->cap = (size_t)1 << 24;
+  q->buf = (char*)std::malloc(q->cap);
+  if (!q->buf) { nb_fastq_close(q); nb::set_error("nb_fastq_open: out of memory"); return NB_ERR_INVALID; }
+  q->reader = std::thread([q] { q->read_loop(); });
+  *out = q; return NB_OK;
+}
+
+int32_t nb_fastq_close(nb_fastq* q) {
+  if (!q) return NB_OK;
+  if (q->reader.joinable()) {
+    { std::lock_guard<std::mutex> lk(q->mu); q->stop = true; }
+    q->cv_space.notify_all();
+    q->reader.join();
+  }
+  for (auto& c : q->chunks) std::free(c.p);
+  for (char* p : q->spare) std::free(p);
+  if (q->gz) gzclose(q->gz);
+  if (q->fd >= 0) ::close(q->fd);
+  std::free(q->buf);
+  delete q;
+  return NB_OK;
+}
+
+int32_t nb_fastq_set_threads(nb_fastq* q, int32_t threads) {
+  if (!q) { nb::set_error("nb_fastq_set_threads: null handle"); return NB_ERR_INVALID; }
+  q->threads = threads < 1 ? 1 : (threads > 256 ? 256 : threads); return NB_OK;
+}
+
+// Stage 2: finds the next up-to-max_reads records. *n_out = records found (0 = end of file), *max_seq_len_out = the
+// longest sequence line among them (so that the caller can size the packed layout to the batch).
+int32_t nb_fastq_index_batch(nb_fastq* q, int64_t max_reads, int64_t* n_out, int32_t* max_seq_len_out) {
+  if (!q || !n_out || max_reads < 0) { nb::set_error("nb_fastq_index_batch: bad arguments"); return NB_ERR_INVALID; }
+  // compact: drop consumed bytes so the offsets recorded below stay valid while the buffer grows
+  if (q->pos > 0) { std::memmove(q->buf, q->buf + q->pos, q->end - q->pos); q->end -= q->pos; q->pos = 0; }
+  q->n_indexed = 0; q->indexed = false; q->next_pos = 0;
+  if (max_reads > 0 && !index_fast(q, max_reads)) {
+    const int32_t rc = index_serial(q, max_reads);
+    if (rc != NB_OK) return rc;
+  }
+  if (!q->src_error.empty()) { nb::set_error("FASTQ read error: " + q->src_error); return NB_ERR_INVALID; }
+  const int64_t n = q->n_indexed;
+  int32_t mx = 0;
+  for (int64_t i = 0; i < n; ++i) mx = std::max<int32_t>(mx, (int32_t)std::min<size_t>(q->seq_e[(size_t)i] - q->seq_b[(size_t)i], (size_t)INT32_MAX));
+  if (max_seq_len_out) *max_seq_len_out = mx;
+  q->longest = mx;
+  q->indexed = true;
+  *n_out = n; return NB_OK;
+}
+
+// Stage 3: packs the records found by the last nb_fastq_index_batch (each output may be NULL; see nb_fastq_next_batch).
+int32_t nb_fastq_pack_batch(nb_fastq* q, int32_t max_len, uint64_t* out_words, uint16_t* out_lens, char* cb_out, int32_t cb_len,
+                            char* umi_out, int32_t umi_len, char* cbqual_out) {
+  if (!q || !q->indexed) { nb::set_error("nb_fastq_pack_batch: no indexed batch"); return NB_ERR_INVALID; }
+  if (out_words && (max_len < 1 || max_len > 65535)) { nb::set_error("nb_fastq_pack_batch: max_len out of range"); return NB_ERR_INVALID; }
+  const int64_t n = q->n_indexed;
+  const int nwb = (max_len + 31) / 32; const int64_t stride = out_words ? nb_packed_stride_words(max_len) : 0;
+  const char* base = q->buf;
   const int T = (int)std::min<int64_t>(q->threads, std::max<int64_t>(1, n / 4096));
   std::vector<int64_t> bad((size_t)T, -1); std::vector<int> bad_kind((size_t)T, 0);
-  auto work = [&](int t) {
+  parallel_for(T, [&](int t) {
     const int64_t lo = n * t / T, hi = n * (t + 1) / T;
     for (int64_t i = lo; i < hi; ++i) {
       const char* b = base + q->seq_b[(size_t)i]; const int64_t L = (int64_t)(q->seq_e[(size_t)i] - q->seq_b[(size_t)i]);
@@ -137,9 +362,7 @@ int32_t nb_fastq_next_batch(nb_fastq* q, int64_t max_reads, int32_t max_len, uin
         if (out_lens) out_lens[i] = (uint16_t)L;
       }
     }
-  };
-  if (T <= 1) work(0);
-  else { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(work, t); work(0); for (auto& x : th) x.join(); }
+  });
   for (int t = 0; t < T; ++t) if (bad[(size_t)t] >= 0) {
       const std::string rec = std::to_string(q->record + bad[(size_t)t]);
       if (bad_kind[(size_t)t] == 1) { nb::set_error("FASTQ record " + rec + ": R1 shorter than cb_len + umi_len"); return NB_ERR_INVALID; }
@@ -147,7 +370,60 @@ int32_t nb_fastq_next_batch(nb_fastq* q, int64_t max_reads, int32_t max_len, uin
       nb::set_error("FASTQ record " + rec + ": read longer than max_len " + std::to_string(max_len)); return NB_ERR_UNSUPPORTED;
     }
   q->record += n;
-  *n_out = n; return NB_OK;
+  q->pos = q->next_pos;
+  q->indexed = false;
+  return NB_OK;
+}
+
+// The streaming entry point of align.py: up to max_reads records, indexed and packed in cache-sized sub-batches (the text
+// of a sub-batch is packed while it is still in the host caches), all at the layout of ONE max_len = the longest read of
+// the first sub-batch, reported in *max_len_out. The batch ends early, before a sub-batch that holds a longer read (that
+// sub-batch stays indexed and opens the next call), so out_words needs max_reads * nb_packed_stride_words(cap_len) words
+// where cap_len is the longest read the caller accepts. Other outputs as for nb_fastq_next_batch.
+int32_t nb_fastq_next_batch_tight(nb_fastq* q, int64_t max_reads, int32_t cap_len, uint64_t* out_words, uint16_t* out_lens,
+                                  int64_t* n_out, int32_t* max_len_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len,
+                                  char* cbqual_out) {
+  if (!q || !n_out || !max_len_out || max_reads < 0) { nb::set_error("nb_fastq_next_batch_tight: bad arguments"); return NB_ERR_INVALID; }
+  constexpr int64_t SUB = 32768;
+  int64_t n = 0; int32_t batch_len = 0;
+  while (n < max_reads) {
+    int64_t m = q->n_indexed; int32_t longest = q->longest;
+    if (q->indexed && m > max_reads - n) {
+      if (n > 0) break;      // a pending sub-batch larger than the room left: it opens the next call
+      q->indexed = false;    // (nothing is consumed until a batch is packed: index again, smaller)
+    }
+    if (!q->indexed) {
+      const int32_t rc = nb_fastq_index_batch(q, std::min<int64_t>(SUB, max_reads - n), &m, &longest);
+      if (rc != NB_OK) return rc;
+      if (m == 0) { q->indexed = false; break; }
+    }
+    if (out_words) {
+      if (longest > cap_len) { nb::set_error("FASTQ read of " + std::to_string(longest) + " bases: longer than the supported " + std::to_string(cap_len)); return NB_ERR_UNSUPPORTED; }
+      if (n == 0) batch_len = std::max<int32_t>(longest, 1);
+      else if (longest > batch_len) break;
+    }
+    const int64_t stride = out_words ? nb_packed_stride_words(batch_len) : 0;
+    const int32_t rc = nb_fastq_pack_batch(q, out_words ? batch_len : 1, out_words ? out_words + n * stride : nullptr, out_lens ? out_lens + n : nullptr,
+                                           cb_out ? cb_out + n * cb_len : nullptr, cb_len, umi_out ? umi_out + n * umi_len : nullptr, umi_len,
+                                           cbqual_out ? cbqual_out + n * cb_len : nullptr);
+    if (rc != NB_OK) return rc;
+    n += m;
+  }
+  *n_out = n; *max_len_out = batch_len;
+  return NB_OK;
+}
+
+// Reads up to max_reads records; *n_out = records read (0 = end of file).
+//   out_words != NULL: the whole sequence line is packed at stride nb_packed_stride_words(max_len), length to out_lens.
+//   cb_out / umi_out != NULL: bases [0, cb_len) and [cb_len, cb_len + umi_len) of the sequence line are copied, fixed
+//   width, to cb_out[i * cb_len] / umi_out[i * umi_len] (the 10x R1 layout); cbqual_out != NULL additionally receives
+//   the quality characters of the CB bases (for the lowest-quality tie-break of the whitelist correction).
+int32_t nb_fastq_next_batch(nb_fastq* q, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,
+                            int64_t* n_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len, char* cbqual_out) {
+  if (!q || !n_out || max_reads < 0) { nb::set_error("nb_fastq_next_batch: bad arguments"); return NB_ERR_INVALID; }
+  int32_t rc = nb_fastq_index_batch(q, max_reads, n_out, nullptr);
+  if (rc != NB_OK) return rc;
+  return nb_fastq_pack_batch(q, max_len, out_words, out_lens, cb_out, cb_len, umi_out, umi_len, cbqual_out);
 }
 
 }  // extern "C"

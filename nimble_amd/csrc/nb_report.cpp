@@ -28,25 +28,61 @@ const char* const kNA[] = {"", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN",
                            "NULL", "NaN", "None", "n/a", "nan", "null"};
 
 bool is_na(const char* b, size_t n) {
+  if (n > 8) return false;
+  if (n) switch (b[0]) { case '#': case '-': case '1': case '<': case 'N': case 'n': break; default: return false; }
   for (const char* s : kNA) if (std::strlen(s) == n && std::memcmp(s, b, n) == 0) return true;
   return false;
 }
 
+// String interner without per-string heap objects: bytes live in one arena, lookups go through an open-addressing table
+// of 64-bit hashes (the per-row cost of `report` is three of these lookups, so this is the hot structure of the parser).
 struct Interner {
-  std::unordered_map<std::string, uint32_t> map;
-  std::vector<std::string> strs;
-  uint32_t get(const std::string& s) {
-    auto it = map.find(s);
-    if (it != map.end()) return it->second;
-    const uint32_t id = (uint32_t)strs.size();
-    map.emplace(s, id); strs.push_back(s); return id;
+  std::vector<char> arena;
+  std::vector<uint64_t> off;        // off[id] .. off[id + 1]
+  std::vector<uint64_t> hashes;     // per id
+  std::vector<uint32_t> slots;      // id + 1, 0 = empty
+  uint64_t mask = 0;
+  Interner() { off.push_back(0); slots.assign(1 << 12, 0); mask = slots.size() - 1; }
+  static uint64_t hash(const char* b, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xD6E8FEB86659FD93ull);
+    while (n >= 8) { uint64_t w; std::memcpy(&w, b, 8); h = (h ^ w) * 0xD6E8FEB86659FD93ull; h ^= h >> 32; b += 8; n -= 8; }
+    uint64_t w = 0; std::memcpy(&w, b, n); h = (h ^ w) * 0xD6E8FEB86659FD93ull; h ^= h >> 29;
+    return h * 0x9E3779B97F4A7C15ull;
   }
-  // rank[id] = position of strs[id] in lexicographic (byte) order — Python's str ordering for the ASCII data at hand
+  size_t size() const { return hashes.size(); }
+  const char* ptr(uint32_t id) const { return arena.data() + off[id]; }
+  size_t len(uint32_t id) const { return (size_t)(off[id + 1] - off[id]); }
+  std::string str(uint32_t id) const { return std::string(ptr(id), len(id)); }
+  void grow() {
+    std::vector<uint32_t> ns(slots.size() * 2, 0); const uint64_t nm = ns.size() - 1;
+    for (uint32_t id = 0; id < hashes.size(); ++id) { uint64_t p = (hashes[id] >> 20) & nm; while (ns[p]) p = (p + 1) & nm; ns[p] = id + 1; }
+    slots.swap(ns); mask = nm;
+  }
+  uint32_t get(const char* b, size_t n) {
+    const uint64_t h = hash(b, n);
+    uint64_t p = (h >> 20) & mask;
+    for (;;) {
+      const uint32_t s = slots[p];
+      if (!s) break;
+      const uint32_t id = s - 1;
+      if (hashes[id] == h && len(id) == n && std::memcmp(ptr(id), b, n) == 0) return id;
+      p = (p + 1) & mask;
+    }
+    const uint32_t id = (uint32_t)hashes.size();
+    slots[p] = id + 1; hashes.push_back(h);
+    arena.insert(arena.end(), b, b + n); off.push_back(arena.size());
+    if (hashes.size() * 2 > slots.size()) grow();
+    return id;
+  }
+  uint32_t get(const std::string& s) { return get(s.data(), s.size()); }
+  // rank[id] = position of the string in lexicographic (byte) order — Python's str ordering for the ASCII data at hand
   std::vector<uint32_t> ranks() const {
-    std::vector<uint32_t> order(strs.size());
+    std::vector<uint32_t> order(size());
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return strs[a] < strs[b]; });
-    std::vector<uint32_t> r(strs.size());
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+      const size_t lx = len(x), ly = len(y); const int c = std::memcmp(ptr(x), ptr(y), std::min(lx, ly));
+      return c ? c < 0 : lx < ly; });
+    std::vector<uint32_t> r(size());
     for (uint32_t i = 0; i < order.size(); ++i) r[order[i]] = i;
     return r;
   }
@@ -85,6 +121,10 @@ std::string quote_minimal(const std::string& f) {   // csv.QUOTE_MINIMAL with de
 // feat_by_rank (strings in lexicographic order), umi is any key that identifies the UMI (only grouping matters: the
 // output is ordered by (cell, feature) and integer scores do not depend on summation order; for float scores the TSV
 // path passes the rank of the UMI string, which reproduces pandas' group order).
+//
+// Cost model: most UMIs are one row; the outcome of a one-row UMI depends only on (feature string, score), so those are
+// memoised and the general thresholding loop runs for multi-row UMIs only. Results (surviving feature lists) are interned;
+// counting uses that the rows arrive sorted by cell, so each cell's results are tallied in a small local vector.
 int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& cb_by_rank, const std::vector<std::string>& feat_by_rank,
                        bool any_float, double threshold, int32_t disable_thresholding, const char* output_path, int64_t* status_out) {
   auto write_empty = [&]() -> int32_t {
@@ -101,6 +141,7 @@ int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& c
     return a.seq < b.seq; });
   struct Row { uint32_t cb; uint64_t umi; uint32_t feat; int64_t iscore; double fscore; };
   std::vector<Row> rows;
+  rows.reserve(recs.size());
   for (size_t i = 0; i < recs.size();) {
     size_t j = i; int64_t is = 0; Kahan k;
     while (j < recs.size() && recs[j].cb == recs[i].cb && recs[j].umi == recs[i].umi && recs[j].feat == recs[i].feat) {
@@ -114,24 +155,27 @@ int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& c
   std::vector<std::vector<uint32_t>> split(feat_by_rank.size());
   for (size_t f = 0; f < feat_by_rank.size(); ++f) {
     const std::string& s = feat_by_rank[f]; size_t p = 0;
-    for (size_t i = 0; i <= s.size(); ++i) if (i == s.size() || s[i] == ',') { split[f].push_back(singles.get(s.substr(p, i - p))); p = i + 1; }
+    for (size_t i = 0; i <= s.size(); ++i) if (i == s.size() || s[i] == ',') { split[f].push_back(singles.get(s.data() + p, i - p)); p = i + 1; }
   }
   const std::vector<uint32_t> rsingle = singles.ranks();
 
-  // ---- per (cb, umi): thresholding + intersection ----
-  std::unordered_map<std::string, int64_t> counts;   // key = cb \x01 feature-string
-  int64_t dropped = 0; bool any_umi = false;
-  std::vector<uint32_t> fid; std::vector<Kahan> sums; std::vector<char> present, drop, keepset, inter;
-  fid.reserve(64);
-  for (size_t i = 0; i < rows.size();) {
-    size_t j = i;
-    while (j < rows.size() && rows[j].cb == rows[i].cb && rows[j].umi == rows[i].umi) ++j;
+  // results: surviving single-feature lists (ordered by rank), interned through their byte image
+  Interner results;
+  auto intern_result = [&](std::vector<uint32_t>& res) -> uint32_t {
+    std::sort(res.begin(), res.end(), [&](uint32_t a, uint32_t b) { return rsingle[a] < rsingle[b]; });
+    return results.get((const char*)res.data(), res.size() * sizeof(uint32_t));
+  };
+  constexpr int32_t NOTHING = -1, EMPTY_INTERSECTION = -2;   // outcome codes beside result ids >= 0
+
+  // ---- per (cb, umi): thresholding + intersection -> outcome ----
+  std::vector<uint32_t> fid, res; std::vector<Kahan> sums; std::vector<char> present, drop, nd, survivors, keepset, inter;
+  auto outcome_of = [&](size_t i, size_t j) -> int32_t {
     // local dense ids of the single features in this group
     fid.clear();
     for (size_t r = i; r < j; ++r) for (uint32_t f : split[rows[r].feat]) if (std::find(fid.begin(), fid.end(), f) == fid.end()) fid.push_back(f);
     const size_t nf = fid.size();
     auto local = [&](uint32_t f) { return (size_t)(std::find(fid.begin(), fid.end(), f) - fid.begin()); };
-    std::vector<char> survivors(nf, 1);
+    survivors.assign(nf, 1);
     if (!disable_thresholding) {
       drop.assign(nf, 0);
       auto shares = [&](bool& any_row, double& ftotal, int64_t& itotal) {
@@ -153,7 +197,7 @@ int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& c
         for (size_t l = 0; l < nf; ++l) have_any |= present[l] != 0;
         if (!have_any) { std::fill(survivors.begin(), survivors.end(), 0); break; }
         const double tot = any_float ? ftotal : (double)itotal;
-        bool any_drop = false; std::vector<char> nd(nf, 0);
+        bool any_drop = false; nd.assign(nf, 0);
         for (size_t l = 0; l < nf; ++l) if (present[l] && (sums[l].s / tot < threshold)) { nd[l] = 1; any_drop = true; }
         if (!any_drop) { for (size_t l = 0; l < nf; ++l) survivors[l] = present[l]; break; }
         drop = nd;                                  // only THIS round's to_drop is excluded (utils.py:159)
@@ -170,34 +214,69 @@ int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& c
       any_kept = true;
       for (size_t l = 0; l < nf; ++l) inter[l] = inter[l] && keepset[l];
     }
-    if (any_kept) {
-      any_umi = true;
-      std::vector<uint32_t> res;
-      for (size_t l = 0; l < nf; ++l) if (inter[l]) res.push_back(fid[l]);
-      if (res.empty()) ++dropped;
-      else {
-        std::sort(res.begin(), res.end(), [&](uint32_t a, uint32_t b) { return rsingle[a] < rsingle[b]; });
-        std::string key = cb_by_rank[rows[i].cb]; key += '\x01';
-        for (size_t t = 0; t < res.size(); ++t) { if (t) key += ','; key += singles.strs[res[t]]; }
-        ++counts[key];
-      }
+    if (!any_kept) return NOTHING;
+    res.clear();
+    for (size_t l = 0; l < nf; ++l) if (inter[l]) res.push_back(fid[l]);
+    if (res.empty()) return EMPTY_INTERSECTION;
+    return (int32_t)intern_result(res);
+  };
+
+  std::unordered_map<uint64_t, int32_t> single_row_memo;   // (feature string, score) -> outcome of a one-row UMI
+  struct Tally { uint32_t cb, result; int64_t count; };
+  std::vector<Tally> tallies; std::vector<uint32_t> cell_results;
+  int64_t dropped = 0; bool any_umi = false;
+  auto flush_cell = [&](uint32_t cb) {
+    std::sort(cell_results.begin(), cell_results.end());
+    for (size_t a = 0; a < cell_results.size();) {
+      size_t b = a; while (b < cell_results.size() && cell_results[b] == cell_results[a]) ++b;
+      tallies.push_back(Tally{cb, cell_results[a], (int64_t)(b - a)}); a = b;
     }
+    cell_results.clear();
+  };
+  for (size_t i = 0; i < rows.size();) {
+    size_t j = i;
+    while (j < rows.size() && rows[j].cb == rows[i].cb && rows[j].umi == rows[i].umi) ++j;
+    int32_t oc;
+    if (j == i + 1 && !any_float && rows[i].iscore >= 0 && rows[i].iscore < ((int64_t)1 << 31)) {
+      const uint64_t key = (uint64_t)rows[i].feat << 32 | (uint64_t)rows[i].iscore;
+      auto it = single_row_memo.find(key);
+      if (it == single_row_memo.end()) it = single_row_memo.emplace(key, outcome_of(i, j)).first;
+      oc = it->second;
+    } else {
+      oc = outcome_of(i, j);
+    }
+    if (oc != NOTHING) any_umi = true;
+    if (oc == EMPTY_INTERSECTION) ++dropped;
+    else if (oc >= 0) cell_results.push_back((uint32_t)oc);
+    if (j == rows.size() || rows[j].cb != rows[i].cb) flush_cell(rows[i].cb);
     i = j;
   }
   if (!any_umi) return write_empty();
   status_out[1] = dropped;
-  std::vector<std::pair<std::string, int64_t>> out(counts.begin(), counts.end());
-  std::sort(out.begin(), out.end(), [](const auto& a, const auto& b) {   // (cell_barcode, feature) lexicographic
-    const size_t pa = a.first.find('\x01'), pb = b.first.find('\x01');
-    const int c = a.first.compare(0, pa, b.first, 0, pb);
-    if (c) return c < 0;
-    return a.first.compare(pa + 1, std::string::npos, b.first, pb + 1, std::string::npos) < 0; });
+  // result strings and their lexicographic ranks; output ordered by (cell_barcode, feature)
+  std::vector<std::string> result_str(results.size());
+  for (uint32_t r = 0; r < results.size(); ++r) {
+    const uint32_t* ids = (const uint32_t*)results.ptr(r); const size_t n = results.len(r) / sizeof(uint32_t);
+    std::string& o = result_str[r];
+    for (size_t t = 0; t < n; ++t) { uint32_t id; std::memcpy(&id, (const char*)ids + t * sizeof(uint32_t), sizeof id); if (t) o += ','; o.append(singles.ptr(id), singles.len(id)); }
+  }
+  std::vector<uint32_t> order(results.size()), rrank(results.size());
+  for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return result_str[a] < result_str[b]; });
+  for (uint32_t i = 0; i < order.size(); ++i) rrank[order[i]] = i;
+  std::sort(tallies.begin(), tallies.end(), [&](const Tally& a, const Tally& b) { return a.cb != b.cb ? a.cb < b.cb : rrank[a.result] < rrank[b.result]; });
   FILE* o = std::fopen(output_path, "wb");
   if (!o) { nb::set_error("report: cannot write output"); return NB_ERR_INVALID; }
-  for (const auto& kv : out) {
-    const size_t p = kv.first.find('\x01');
-    const std::string cb = kv.first.substr(0, p), feat = kv.first.substr(p + 1);
-    std::fprintf(o, "%s\t%lld\t%s\n", quote_minimal(feat).c_str(), (long long)kv.second, quote_minimal(cb).c_str());
+  std::vector<char> obuf(1 << 22); std::setvbuf(o, obuf.data(), _IOFBF, obuf.size());
+  std::vector<std::string> quoted_result(results.size());
+  for (uint32_t r = 0; r < results.size(); ++r) quoted_result[r] = quote_minimal(result_str[r]);
+  std::string quoted_cb; uint32_t quoted_cb_of = UINT32_MAX;
+  for (const Tally& t : tallies) {
+    if (t.cb != quoted_cb_of) { quoted_cb = quote_minimal(cb_by_rank[t.cb]); quoted_cb_of = t.cb; }
+    std::fwrite(quoted_result[t.result].data(), 1, quoted_result[t.result].size(), o);
+    std::fprintf(o, "\t%lld\t", (long long)t.count);
+    std::fwrite(quoted_cb.data(), 1, quoted_cb.size(), o);
+    std::fputc('\n', o);
   }
   std::fclose(o);
   return NB_OK;
@@ -223,7 +302,7 @@ int32_t nb_report_tsv(const char* input_path, const char* output_path, double th
   // ---- stream lines ----
   std::vector<char> buf(1 << 22); size_t have = 0; bool eof = false;
   std::string line; bool header_done = false; int ix[4] = {-1, -1, -1, -1};
-  Interner cbs, umis, feats;
+  Interner cbs, umis, feats, raw_feats; std::vector<uint32_t> canon_of;
   std::vector<Rec> recs; bool any_float = false; uint32_t seq = 0;
   std::vector<std::string> parts;
   auto handle_line = [&](const char* b, size_t n) -> int {
@@ -253,13 +332,17 @@ int32_t nb_report_tsv(const char* input_path, const char* output_path, double th
       if (end == tok.c_str() || *end != '\0') return -2;
       any_float = true; r.iscore = INT64_MIN;
     } else r.fscore = (double)r.iscore;
-    // sort the features inside the row (__main__.py:248)
-    parts.clear(); size_t p = 0;
-    for (size_t i = 0; i <= fn[0]; ++i) if (i == fn[0] || fb[0][i] == ',') { parts.emplace_back(fb[0] + p, i - p); p = i + 1; }
-    std::sort(parts.begin(), parts.end());
-    std::string joined;
-    for (size_t i = 0; i < parts.size(); ++i) { if (i) joined += ','; joined += parts[i]; }
-    r.feat = feats.get(joined); r.cb = cbs.get(std::string(fb[2], fn[2])); r.umi = umis.get(std::string(fb[3], fn[3]));
+    // sort the features inside the row (__main__.py:248): once per distinct raw string
+    const uint32_t raw = raw_feats.get(fb[0], fn[0]);
+    if (raw == canon_of.size()) {
+      parts.clear(); size_t p = 0;
+      for (size_t i = 0; i <= fn[0]; ++i) if (i == fn[0] || fb[0][i] == ',') { parts.emplace_back(fb[0] + p, i - p); p = i + 1; }
+      std::sort(parts.begin(), parts.end());
+      std::string joined;
+      for (size_t i = 0; i < parts.size(); ++i) { if (i) joined += ','; joined += parts[i]; }
+      canon_of.push_back(feats.get(joined));
+    }
+    r.feat = canon_of[raw]; r.cb = cbs.get(fb[2], fn[2]); r.umi = umis.get(fb[3], fn[3]);
     recs.push_back(r); return 0;
   };
   bool any_bytes = false, any_body = false; int perr = 0;
@@ -287,11 +370,14 @@ int32_t nb_report_tsv(const char* input_path, const char* output_path, double th
   if (!any_bytes || recs.empty()) return write_empty();
 
   // strings -> ranks (pandas sorts group keys lexicographically), then the shared reduction
-  const std::vector<uint32_t> rcb = cbs.ranks(), rumi = umis.ranks(), rfeat = feats.ranks();
-  std::vector<std::string> cb_by_rank(cbs.strs.size()), feat_by_rank(feats.strs.size());
-  for (size_t i = 0; i < cbs.strs.size(); ++i) cb_by_rank[rcb[i]] = cbs.strs[i];
-  for (size_t i = 0; i < feats.strs.size(); ++i) feat_by_rank[rfeat[i]] = feats.strs[i];
-  for (auto& r : recs) { r.cb = rcb[r.cb]; r.umi = rumi[(size_t)r.umi]; r.feat = rfeat[r.feat]; }
+  // (the UMI order only matters for float scores, whose sums depend on the group order; integers skip that sort)
+  const std::vector<uint32_t> rcb = cbs.ranks(), rfeat = feats.ranks();
+  std::vector<uint32_t> rumi;
+  if (any_float) rumi = umis.ranks();
+  std::vector<std::string> cb_by_rank(cbs.size()), feat_by_rank(feats.size());
+  for (uint32_t i = 0; i < cbs.size(); ++i) cb_by_rank[rcb[i]] = cbs.str(i);
+  for (uint32_t i = 0; i < feats.size(); ++i) feat_by_rank[rfeat[i]] = feats.str(i);
+  for (auto& r : recs) { r.cb = rcb[r.cb]; if (any_float) r.umi = rumi[(size_t)r.umi]; r.feat = rfeat[r.feat]; }
   return reduce_records(recs, cb_by_rank, feat_by_rank, any_float, threshold, disable_thresholding, output_path, status_out);
 }
 
@@ -305,12 +391,12 @@ int32_t nb_report_rows(int64_t n, const uint32_t* cb_ids, const uint64_t* umi_ke
   status_out[0] = 0; status_out[1] = 0;
   Interner cbs, feats;
   std::vector<uint32_t> cb_of((size_t)n_cb), feat_of((size_t)n_feat);
-  for (int64_t i = 0; i < n_cb; ++i) cb_of[(size_t)i] = cbs.get(cb_strings[i]);
-  for (int64_t i = 0; i < n_feat; ++i) feat_of[(size_t)i] = feats.get(feat_strings[i]);
+  for (int64_t i = 0; i < n_cb; ++i) cb_of[(size_t)i] = cbs.get(cb_strings[i], std::strlen(cb_strings[i]));
+  for (int64_t i = 0; i < n_feat; ++i) feat_of[(size_t)i] = feats.get(feat_strings[i], std::strlen(feat_strings[i]));
   const std::vector<uint32_t> rcb = cbs.ranks(), rfeat = feats.ranks();
-  std::vector<std::string> cb_by_rank(cbs.strs.size()), feat_by_rank(feats.strs.size());
-  for (size_t i = 0; i < cbs.strs.size(); ++i) cb_by_rank[rcb[i]] = cbs.strs[i];
-  for (size_t i = 0; i < feats.strs.size(); ++i) feat_by_rank[rfeat[i]] = feats.strs[i];
+  std::vector<std::string> cb_by_rank(cbs.size()), feat_by_rank(feats.size());
+  for (uint32_t i = 0; i < cbs.size(); ++i) cb_by_rank[rcb[i]] = cbs.str(i);
+  for (uint32_t i = 0; i < feats.size(); ++i) feat_by_rank[rfeat[i]] = feats.str(i);
   std::vector<Rec> recs; recs.reserve((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
     if ((int64_t)cb_ids[i] >= n_cb || (int64_t)feat_ids[i] >= n_feat) { nb::set_error("nb_report_rows: id out of range"); return NB_ERR_INVALID; }

@@ -46,6 +46,18 @@ def pack_reads(reads, max_len=None):
     return words, lens
 
 
+def unpack_read(words, length, max_len):
+    """Inverse of the packing for one read (row of `words` at the layout of `max_len`): 'ACGT' string, N where masked."""
+    nwb = (int(max_len) + 31) // 32
+    out = []
+    for j in range(int(length)):
+        if (int(words[nwb + (j >> 6)]) >> (j & 63)) & 1:
+            out.append("N")
+        else:
+            out.append("ACGT"[(int(words[j >> 5]) >> ((j & 31) * 2)) & 3])
+    return "".join(out)
+
+
 class Index:
     """Coloured k-mer index of one reference library (host build; docs/SPEC.md §2)."""
 

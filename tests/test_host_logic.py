@@ -90,6 +90,77 @@ def test_fastq_ingest_plain_and_gzip(built, tmp_path):
         r.next_batch(5, 20)
 
 
+def _drain(reader, batch, cap_len):
+    reads, lens = [], []
+    while True:
+        b = reader.next_batch(batch, cap_len)
+        if b["n"] == 0:
+            return reads, lens
+        w, l = b["words"], b["lens"]
+        assert w.shape == (b["n"], engine.packed_stride_words(b["max_len"])) and int(l.max()) <= b["max_len"]
+        for i in range(b["n"]):
+            reads.append(engine.unpack_read(w[i], int(l[i]), b["max_len"]))
+        lens.extend(int(x) for x in l)
+
+
+@pytest.mark.parametrize("newline,blank,trailing", [("\n", False, True), ("\r\n", False, True), ("\n", True, True), ("\n", False, False)])
+def test_fastq_ingest_framing_variants(built, tmp_path, newline, blank, trailing):
+    """Parallel strict-framing indexer and the serial walker (blank lines between records, CRLF, no final newline) must give
+    the same records; batches are packed at the layout of their own longest read and end early before a longer one."""
+    from nimble_amd.align import FastqReader
+    rng = np.random.default_rng(7)
+    n = 100_000
+    lens = rng.integers(0, 61, n)
+    lens[70_000] = 97                      # one long read deep in the file: forces an early batch end + a wider layout
+    seqs = ["".join("ACGTNacgt"[c] for c in rng.integers(0, 9, L)) for L in lens]
+    recs = [f"@r{i} x{newline}{s}{newline}+{newline}{'I' * len(s)}{newline}" for i, s in enumerate(seqs)]
+    if blank:
+        recs[1000] = newline + recs[1000]
+        recs[50_000] = newline + newline + recs[50_000]
+    text = "".join(recs)
+    if not trailing:
+        text = text[:-len(newline)]
+    elif blank:
+        text += newline
+    p = tmp_path / "v.fastq"
+    p.write_bytes(text.encode())
+    for threads, batch in ((1, 1 << 20), (4, 40_000), (3, 7)):
+        if batch == 7 and n > 20_000:
+            continue
+        r = FastqReader(str(p), threads)
+        got, got_l = _drain(r, batch, 128)
+        r.close()
+        assert got_l == [int(x) for x in lens]
+        assert got == [s.upper() for s in seqs]
+    r = FastqReader(str(p), 2)
+    with pytest.raises(engine._lib.NimbleError):
+        _drain(r, 1 << 20, 96)             # the 97-base read exceeds the cap
+    r.close()
+
+
+def test_fastq_ingest_errors(built, tmp_path):
+    from nimble_amd.align import FastqReader
+    cases = {"no_plus": "@a\nACGT\nIIII\n@b\nAC\n+\nII\n", "truncated": "@a\nACGT\n+\nIIII\n@b\nAC\n", "no_at": "a\nACGT\n+\nIIII\n"}
+    for name, text in cases.items():
+        p = tmp_path / f"{name}.fastq"
+        p.write_text(text)
+        r = FastqReader(str(p), 2)
+        with pytest.raises(engine._lib.NimbleError):
+            _drain(r, 100, 50)
+        r.close()
+    z = tmp_path / "corrupt.fastq.gz"
+    good = tmp_path / "good.fastq.gz"
+    with gzip.open(good, "wt") as f:
+        f.write("".join(f"@r{i}\n{'ACGT' * 20}\n+\n{'I' * 80}\n" for i in range(20000)))
+    raw = bytearray(good.read_bytes())
+    raw[len(raw) // 2] ^= 0xFF
+    z.write_bytes(bytes(raw[: len(raw) - 40]))
+    r = FastqReader(str(z), 2)
+    with pytest.raises(engine._lib.NimbleError):
+        _drain(r, 1 << 20, 100)
+    r.close()
+
+
 def test_barcode_correction_rule():
     wl = {"AAAA", "AAAC", "CAAT", "GGGG"}
     c = barcodes.BarcodeCorrector(wl)

@@ -31,8 +31,8 @@ def test_host_code_under_sanitizers(tmp_path):
     case = json.load(open(os.path.join(ROOT, "tests", "golden", "report_cases.json")))[-1]
     (tmp_path / "in.tsv").write_text(case["input"])
     (tmp_path / "wl.txt").write_text("\n".join("".join("ACGT"[c] for c in rng.integers(0, 4, 8)) for _ in range(2000)) + "\n")
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
-                    "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-o", str(exe)] + srcs + ["-lz"],
-                   check=True, capture_output=True)
-    r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "sanitize ok" in r.stdout, r.stdout + r.stderr
+    for flags in (["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], ["-fsanitize=thread"]):   # the readers are multi-threaded
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17"] + flags + ["-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-o", str(exe)]
+                       + srcs + ["-lz"], check=True, capture_output=True)
+        r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "sanitize ok" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
