@@ -158,6 +158,13 @@ int32_t nb_bam_open(const char* path, nb_bam** out);
 int32_t nb_bam_close(nb_bam* bam);
 int32_t nb_bam_next_batch(nb_bam* bam, int64_t max_templates, int32_t max_len, uint64_t* r1_words, uint16_t* r1_lens, uint64_t* r2_words,
                           uint16_t* r2_lens, char* cb_out, char* ub_out, int32_t tag_width, int64_t* n_out, int32_t* paired_out);
+/* worker threads for BGZF inflate and packing (the reference's -c/--num_cores); default 1 */
+int32_t nb_bam_set_threads(nb_bam* bam, int32_t threads);
+/* streaming form used by align.py (see nb_fastq_next_batch_tight): r1 packed at the layout of *len1_out, r2 at *len2_out;
+ * the word buffers hold max_templates * nb_packed_stride_words(cap_len) words. */
+int32_t nb_bam_next_batch_tight(nb_bam* bam, int64_t max_templates, int32_t cap_len, uint64_t* r1_words, uint16_t* r1_lens,
+                                uint64_t* r2_words, uint16_t* r2_lens, char* cb_out, char* ub_out, int32_t tag_width, int64_t* n_out,
+                                int32_t* len1_out, int32_t* len2_out, int32_t* paired_out);
 
 /* ---- 10x cell-barcode whitelist correction (host): restates correct_cell_barcode,
  * /root/reference/nimble/fastq_barcode_processor.py:73-128 (exact -> Hamming-1 candidates -> lowest quality at the

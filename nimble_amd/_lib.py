@@ -71,6 +71,9 @@ SIGNATURES = {
                                          ct.c_void_p]),
     "nb_bam_open": (ct.c_int32, [ct.c_char_p, ct.POINTER(ct.c_void_p)]),
     "nb_bam_close": (ct.c_int32, [ct.c_void_p]),
+    "nb_bam_set_threads": (ct.c_int32, [ct.c_void_p, ct.c_int32]),
+    "nb_bam_next_batch_tight": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.c_int32, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
+                                             ct.c_void_p, ct.c_int32, c_i64p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     "nb_bam_next_batch": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.c_int32, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
                                        ct.c_void_p, ct.c_int32, c_i64p, ct.POINTER(ct.c_int32)]),
     "nb_whitelist_load": (ct.c_int32, [ct.c_char_p, ct.POINTER(ct.c_void_p)]),

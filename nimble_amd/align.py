@@ -27,7 +27,7 @@ from . import _lib, engine, fused
 from .library import Library
 from .utils import append_path_string, parse_trim
 
-BATCH_READS = 1 << 20
+BATCH_READS = int(os.environ.get("NB_BATCH_READS", 1 << 18))   # templates per GPU launch; host buffers of this size stay cache- and TLB-friendly
 MAX_READ_LEN = 339      # NB_MAX_POSITIONS + k - 1 at k = 20
 COV_COLUMNS = ["r1_forward_score", "r1_reverse_score", "r2_forward_score", "r2_reverse_score"]
 
@@ -95,24 +95,34 @@ class FastqReader:
 
 
 class BamReader:
-    """nb_bam_* (csrc/nb_bam.cpp): templates of a BAM in file order, CB/UB tags of r1. No sort needed (see nb_bam.cpp)."""
+    """nb_bam_* (csrc/nb_bam.cpp): templates of a BAM in file order, CB/UB tags of r1. No sort needed (see nb_bam.cpp).
+    Buffers alternate between two sets, as in FastqReader."""
     TAG_WIDTH = 48
 
-    def __init__(self, path):
+    def __init__(self, path, threads=1, pinned=False):
         self._h = ct.c_void_p()
         _lib.check(_lib.lib().nb_bam_open(path.encode(), ct.byref(self._h)))
+        _lib.check(_lib.lib().nb_bam_set_threads(self._h, int(threads)))
+        self._pinned = pinned
+        self._sets, self._turn = {}, 0
+
+    _buffers = FastqReader._buffers
 
     def next_batch(self, max_reads, max_len):
-        stride = engine.packed_stride_words(max_len)
-        w1 = np.zeros((max_reads, stride), dtype=np.uint64); l1 = np.zeros(max_reads, dtype=np.uint16)
-        w2 = np.zeros((max_reads, stride), dtype=np.uint64); l2 = np.zeros(max_reads, dtype=np.uint16)
-        cb = np.zeros((max_reads, self.TAG_WIDTH), dtype="S1"); ub = np.zeros((max_reads, self.TAG_WIDTH), dtype="S1")
-        n, paired = ct.c_int64(), ct.c_int32()
-        _lib.check(_lib.lib().nb_bam_next_batch(self._h, max_reads, max_len, w1.ctypes.data, l1.ctypes.data, w2.ctypes.data, l2.ctypes.data,
-                                                cb.ctypes.data, ub.ctypes.data, self.TAG_WIDTH, ct.byref(n), ct.byref(paired)))
-        k = n.value
-        return {"n": k, "paired": bool(paired.value), "words": w1[:k], "lens": l1[:k], "mate_words": w2[:k], "mate_lens": l2[:k],
-                "cb": cb[:k], "umi": ub[:k]}
+        """dict(n, paired, words, lens, max_len, mate_words, mate_lens, mate_max_len, cb, umi); `max_len` = longest read accepted,
+        the result's max_len / mate_max_len = the layouts the batch is packed at."""
+        self._turn += 1
+        cap = engine.packed_stride_words(max_len)
+        f1 = self._buffers("w1", max_reads, (cap,), np.uint64).reshape(-1); l1 = self._buffers("l1", max_reads, (), np.uint16)
+        f2 = self._buffers("w2", max_reads, (cap,), np.uint64).reshape(-1); l2 = self._buffers("l2", max_reads, (), np.uint16)
+        cb = self._buffers("cb", max_reads, (self.TAG_WIDTH,), "S1"); ub = self._buffers("ub", max_reads, (self.TAG_WIDTH,), "S1")
+        n, paired, len1, len2 = ct.c_int64(), ct.c_int32(), ct.c_int32(), ct.c_int32()
+        _lib.check(_lib.lib().nb_bam_next_batch_tight(self._h, max_reads, max_len, f1.ctypes.data, l1.ctypes.data, f2.ctypes.data, l2.ctypes.data,
+                                                      cb.ctypes.data, ub.ctypes.data, self.TAG_WIDTH, ct.byref(n), ct.byref(len1), ct.byref(len2),
+                                                      ct.byref(paired)))
+        k, s1, s2 = n.value, engine.packed_stride_words(len1.value), engine.packed_stride_words(len2.value)
+        return {"n": k, "paired": bool(paired.value), "words": f1[:k * s1].reshape(k, s1), "lens": l1[:k], "max_len": len1.value,
+                "mate_words": f2[:k * s2].reshape(k, s2), "mate_lens": l2[:k], "mate_max_len": len2.value, "cb": cb[:k], "umi": ub[:k]}
 
     def close(self):
         if self._h:
@@ -292,7 +302,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         corrector = None
         if tenx is not None and tenx.whitelist:
             corrector = NativeWhitelist(tenx.whitelist)
-        bam = BamReader(input[0]) if is_bam else None
+        bam = BamReader(input[0], num_cores, pinned=True) if is_bam else None
         r1 = FastqReader(input[0], num_cores, pinned=True) if not is_bam else None
         r2 = FastqReader(input[1], num_cores, pinned=True) if len(input) == 2 else None
         total, t0 = 0, time.time()
@@ -303,10 +313,10 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
             release the GIL, so parsing batch i+1 overlaps the GPU work and the TSV writing of batch i)."""
             t = time.perf_counter()
             if is_bam:
-                bb = bam.next_batch(min(batch_reads, 1 << 20), MAX_READ_LEN)
+                bb = bam.next_batch(batch_reads, MAX_READ_LEN)
                 b1 = {"cb": bb["cb"], "umi": bb["umi"], "cbq": None}
-                seq = {"n": bb["n"], "words": bb["words"], "lens": bb["lens"]}
-                mate = {"n": bb["n"], "words": bb["mate_words"], "lens": bb["mate_lens"]} if bb["paired"] else None
+                seq = {"n": bb["n"], "words": bb["words"], "lens": bb["lens"], "max_len": bb["max_len"]}
+                mate = {"n": bb["n"], "words": bb["mate_words"], "lens": bb["mate_lens"], "max_len": bb["mate_max_len"]} if bb["paired"] else None
             elif per_read:
                 b1 = r1.next_batch(batch_reads, barcodes_only=True, cb_len=tenx.cb_length, umi_len=tenx.umi_length)
                 seq, mate = r2.next_batch(b1["n"], MAX_READ_LEN) if b1["n"] else {"n": 0}, None
@@ -321,7 +331,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
             if (per_read or paired) and seq["n"] == 0 and not is_bam and r2.next_batch(1, MAX_READ_LEN)["n"]:
                 raise ValueError("R1 and R2 FASTQ files have different numbers of records")
             if per_read and seq["n"]:
-                b1["cb_fixed"], b1["cb_ok"] = corrector.correct(b1["cb"], b1["cbq"]) if corrector else (b1["cb"], None)
+                b1["cb_fixed"], b1["cb_ok"] = corrector.correct(b1["cb"], b1["cbq"]) if corrector else (b1["cb"].copy(), None)
             prof.add("ingest (helper thread)", time.perf_counter() - t)
             return seq, mate, b1
 
@@ -373,7 +383,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
                         snap = run.snapshot()
                     write_jobs.append(writer.submit(_timed, prof, "TSV rows (writer thread)", _write_per_read, run, snap, h_class.numpy().view(np.uint32),
                                                     h_info.numpy().view(np.uint32), h_cov.numpy().view(np.uint64), b1["cb_fixed"], b1["cb_ok"],
-                                                    b1["umi"] if is_bam else b1["umi"].copy()))   # (reader buffers are recycled two batches on)
+                                                    b1["umi"].copy()))   # (reader buffers are recycled two batches on)
             total += n
         with prof("wait for writer"):
             for j in write_jobs:
@@ -452,8 +462,8 @@ def _top_up(reader, batch, want):
 
 
 def _tight(batch):
-    """(words, max_len) of a reader batch at the layout of its own longest read. FASTQ batches arrive that way; BAM batches are
-    packed at MAX_READ_LEN and re-strided here."""
+    """(words, max_len) of a reader batch at the layout of its own longest read (the readers deliver that; a batch packed at
+    MAX_READ_LEN by the plain entry points is re-strided here)."""
     if "max_len" in batch:
         return batch["words"], batch["max_len"]
     max_len = max(int(batch["lens"].max()), 1)

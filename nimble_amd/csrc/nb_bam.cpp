@@ -10,66 +10,180 @@
 //   * a record stored reverse-complemented (0x10) is turned back into the read as sequenced;
 //   * paired records (0x1) must be adjacent mates (first 0x40 then last 0x80, same name): the order samtools sort -n /
 //     collate and the reference's fastq-to-bam produce; anything else is an error, not a silent mis-pairing.
-// BGZF is a series of gzip members; zlib's gzread walks across members transparently.
+// BGZF is a series of gzip members of <= 64 KiB, each carrying its compressed size in a 'BC' extra field (SAM spec §4.1),
+// so members inflate independently: a refill reads a run of whole blocks and inflates them on `threads` workers, each into
+// its own slice of the output (sizes come from the ISIZE trailers), with the CRC of every block checked. A gzip file
+// that is not BGZF (one long member) falls back to zlib's serial gzread. Records are then gathered serially (a walk
+// over the block_size chain plus the mate-adjacency rule) and packed in parallel.
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nb_internal.h"
 
+namespace {
+
+struct Tmpl { size_t a, b; uint32_t a_size, b_size; };   // offsets (into ubuf) and sizes of the record bodies; b = SIZE_MAX when single-end
+
+template <class F>
+void parallel_for(int T, F&& f) {
+  if (T <= 1) { f(0); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)T - 1);
+  for (int t = 1; t < T; ++t) th.emplace_back([&f, t] { f(t); });
+  f(0);
+  for (auto& x : th) x.join();
+}
+
+}  // namespace
+
 struct nb_bam {
-  gzFile f = nullptr;
+  FILE* fp = nullptr;          // BGZF path
+  gzFile gz = nullptr;         // fallback: plain gzip
+  int threads = 1;
+  std::vector<uint8_t> cbuf;   // compressed bytes not yet inflated: [cpos, cend)
+  size_t cpos = 0, cend = 0;
+  bool file_eof = false;
+  std::vector<uint8_t> ubuf;   // inflated bytes: [upos, uend) unconsumed
+  size_t upos = 0, uend = 0;
+  bool eof = false;
+  std::string error;
   int64_t record = 0;
-  bool have_held = false;
-  std::vector<uint8_t> held;   // a record read ahead (mate lookup)
   int paired = -1;             // -1 unknown, 0 single-end, 1 adjacent mates (fixed by the first primary record)
+  // templates gathered but not yet packed (a batch may end before them: see nb_bam_next_batch_tight)
+  std::vector<Tmpl> pend;
+  size_t pend_next_upos = 0;
+  int pend_l1 = 0, pend_l2 = 0;
+  bool have_pend = false;
 };
 
 namespace {
 
-bool read_exact(nb_bam* b, void* dst, size_t n) {
-  size_t got = 0;
-  while (got < n) {
-    const int r = gzread(b->f, (char*)dst + got, (unsigned)std::min<size_t>(n - got, (size_t)1 << 30));
-    if (r <= 0) return false;
-    got += (size_t)r;
-  }
-  return true;
-}
-
 int32_t le32(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-// 1 = record read into rec (without the block_size word), 0 = clean end of file, <0 = error
-int next_record(nb_bam* b, std::vector<uint8_t>& rec) {
-  if (b->have_held) { rec.swap(b->held); b->have_held = false; return 1; }
-  uint8_t szb[4];
-  const int r = gzread(b->f, szb, 4);
-  if (r == 0) return 0;
-  if (r != 4) { nb::set_error("BAM: truncated record header"); return NB_ERR_INVALID; }
-  const int32_t sz = le32(szb);
+constexpr size_t REFILL_COMPRESSED = (size_t)8 << 20;
+
+// size of the BGZF block starting at p (n bytes available), 0 if the header is incomplete, -1 if it is not a BGZF block
+long bgzf_block_size(const uint8_t* p, size_t n) {
+  if (n < 18) return 0;
+  if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return -1;
+  const size_t xlen = le16(p + 10);
+  if (n < 12 + xlen) return 0;
+  for (size_t o = 12; o + 4 <= 12 + xlen;) {
+    const size_t slen = le16(p + o + 2);
+    if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2) return (long)le16(p + o + 4) + 1;
+    o += 4 + slen;
+  }
+  return -1;
+}
+
+// inflate more data behind uend; false at end of file or on error (b->error set)
+bool refill(nb_bam* b) {
+  if (b->eof) return false;
+  if (b->gz) {
+    const size_t want = (size_t)16 << 20;
+    if (b->ubuf.size() < b->uend + want) b->ubuf.resize(b->uend + want);
+    const int r = gzread(b->gz, b->ubuf.data() + b->uend, (unsigned)want);
+    if (r < 0) { int e = 0; const char* m = gzerror(b->gz, &e); b->error = std::string("BAM: gzip stream error: ") + (m ? m : "?"); b->eof = true; return false; }
+    if (r == 0) { b->eof = true; return false; }
+    b->uend += (size_t)r; return true;
+  }
+  struct Blk { size_t coff, csize, uoff, usize; };
+  std::vector<Blk> blks;
+  for (;;) {
+    // top up the compressed window
+    if (!b->file_eof && b->cend - b->cpos < REFILL_COMPRESSED) {
+      if (b->cpos > 0) { std::memmove(b->cbuf.data(), b->cbuf.data() + b->cpos, b->cend - b->cpos); b->cend -= b->cpos; b->cpos = 0; }
+      if (b->cbuf.size() < b->cend + REFILL_COMPRESSED) b->cbuf.resize(b->cend + REFILL_COMPRESSED);
+      const size_t got = std::fread(b->cbuf.data() + b->cend, 1, REFILL_COMPRESSED, b->fp);
+      if (got < REFILL_COMPRESSED) { if (std::ferror(b->fp)) { b->error = "BAM: read error"; b->eof = true; return false; } b->file_eof = true; }
+      b->cend += got;
+    }
+    size_t o = b->cpos, utotal = 0;
+    while (o < b->cend) {
+      const long bs = bgzf_block_size(b->cbuf.data() + o, b->cend - o);
+      if (bs < 0) { b->error = "BAM: corrupt BGZF block header"; b->eof = true; return false; }
+      if (bs == 0 || o + (size_t)bs > b->cend) break;
+      if (bs < 26) { b->error = "BAM: corrupt BGZF block size"; b->eof = true; return false; }
+      const size_t usize = (uint32_t)le32(b->cbuf.data() + o + (size_t)bs - 4);
+      if (usize > 65536) { b->error = "BAM: corrupt BGZF block (ISIZE > 64 KiB)"; b->eof = true; return false; }
+      blks.push_back(Blk{o, (size_t)bs, utotal, usize});
+      utotal += usize; o += (size_t)bs;
+    }
+    if (blks.empty()) {
+      if (b->file_eof) {
+        if (b->cpos < b->cend) { b->error = "BAM: truncated BGZF block"; }
+        b->eof = true; return false;
+      }
+      continue;   // not even one whole block yet: read more
+    }
+    if (b->ubuf.size() < b->uend + utotal) b->ubuf.resize(std::max(b->ubuf.size() * 2, b->uend + utotal));
+    const int T = (int)std::min<size_t>((size_t)b->threads, std::max<size_t>(1, blks.size() / 8));
+    std::vector<int> bad((size_t)T, 0);
+    uint8_t* ub = b->ubuf.data() + b->uend; const uint8_t* cb = b->cbuf.data();
+    parallel_for(T, [&](int t) {
+      z_stream z; std::memset(&z, 0, sizeof z);
+      if (inflateInit2(&z, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
+      for (size_t i = blks.size() * (size_t)t / (size_t)T, e = blks.size() * (size_t)(t + 1) / (size_t)T; i < e; ++i) {
+        const Blk& k = blks[i];
+        if (k.usize == 0) continue;   // (the empty end-of-file marker block)
+        const size_t xlen = le16(cb + k.coff + 10), hdr = 12 + xlen;
+        if (k.csize < hdr + 8) { bad[(size_t)t] = 1; break; }
+        inflateReset(&z);
+        z.next_in = (Bytef*)(cb + k.coff + hdr); z.avail_in = (uInt)(k.csize - hdr - 8);
+        z.next_out = ub + k.uoff; z.avail_out = (uInt)k.usize;
+        const int rc = inflate(&z, Z_FINISH);
+        if (rc != Z_STREAM_END || z.avail_out != 0) { bad[(size_t)t] = 1; break; }
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), ub + k.uoff, (uInt)k.usize) != (uint32_t)le32(cb + k.coff + k.csize - 8)) { bad[(size_t)t] = 1; break; }
+      }
+      inflateEnd(&z);
+    });
+    for (int x : bad) if (x) { b->error = "BAM: corrupt BGZF block (inflate / CRC failure)"; b->eof = true; return false; }
+    b->cpos = o; b->uend += utotal;
+    if (utotal == 0) { blks.clear(); if (b->file_eof && b->cpos == b->cend) { b->eof = true; return false; } continue; }   // only empty (EOF marker) blocks
+    return true;
+  }
+}
+
+// makes [off, off + n) of ubuf valid; false when the file ends first
+bool ensure(nb_bam* b, size_t off, size_t n) {
+  while (b->uend < off + n) if (!refill(b)) return false;
+  return true;
+}
+
+// 1 = record body at [*off, *off + *size) (cursor advanced past it), 0 = clean end of file, <0 = error
+int next_record(nb_bam* b, size_t* cursor, size_t* off, uint32_t* size) {
+  if (!ensure(b, *cursor, 4)) {
+    if (!b->error.empty()) { nb::set_error(b->error); return NB_ERR_INVALID; }
+    if (b->uend > *cursor) { nb::set_error("BAM: truncated record header"); return NB_ERR_INVALID; }
+    return 0;
+  }
+  const int32_t sz = le32(b->ubuf.data() + *cursor);
   if (sz < 32 || sz > (1 << 28)) { nb::set_error("BAM: implausible record size"); return NB_ERR_INVALID; }
-  rec.resize((size_t)sz);
-  if (!read_exact(b, rec.data(), (size_t)sz)) { nb::set_error("BAM: truncated record"); return NB_ERR_INVALID; }
+  if (!ensure(b, *cursor + 4, (size_t)sz)) { nb::set_error(b->error.empty() ? "BAM: truncated record" : b->error); return NB_ERR_INVALID; }
+  *off = *cursor + 4; *size = (uint32_t)sz; *cursor += 4 + (size_t)sz;
   return 1;
 }
 
 struct Fields { uint16_t flag; int32_t l_seq; const uint8_t* name; int l_name; const uint8_t* seq; const uint8_t* tags; const uint8_t* end; };
 
-bool parse(const std::vector<uint8_t>& rec, Fields& f) {
-  const uint8_t* p = rec.data();
+bool parse(const uint8_t* p, size_t size, Fields& f) {
   const int l_read_name = p[8]; const int n_cigar = le16(p + 12);
   f.flag = le16(p + 14); f.l_seq = le32(p + 16);
   size_t off = 32;
   f.name = p + off; f.l_name = l_read_name; off += (size_t)l_read_name;
   off += (size_t)n_cigar * 4;
+  if (f.l_seq < 0) return false;
   f.seq = p + off; off += (size_t)(f.l_seq + 1) / 2;
   off += (size_t)f.l_seq;   // qualities
-  if (f.l_seq < 0 || off > rec.size()) return false;
-  f.tags = p + off; f.end = p + rec.size();
+  if (off > size) return false;
+  f.tags = p + off; f.end = p + size;
   return true;
 }
 
@@ -90,6 +204,7 @@ const char* find_z_tag(const Fields& f, const char* t, size_t* len) {
         const size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4); skip = 5 + es * cnt; break; }
       default: return nullptr;
     }
+    if (skip > (size_t)(f.end - p)) return nullptr;
     p += skip;
   }
   return nullptr;
@@ -98,16 +213,106 @@ const char* find_z_tag(const Fields& f, const char* t, size_t* len) {
 // decode the 4-bit sequence into the packed device layout (restoring the sequenced orientation when 0x10 is set)
 void pack_seq(const Fields& f, int nwb, int64_t stride, uint64_t* w) {
   static const uint8_t code[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};   // "=ACMGRSVTWYHKDBN" -> A C G T else N
-  std::memset(w, 0, (size_t)stride * 8);
   const bool rev = f.flag & 0x10;
   const int L = f.l_seq;
-  for (int j = 0; j < L; ++j) {
-    const int src = rev ? L - 1 - j : j;
-    uint8_t c = code[(f.seq[src >> 1] >> ((src & 1) ? 0 : 4)) & 15];
-    if (c != 4 && rev) c = (uint8_t)(3 - c);
-    if (c == 4) w[nwb + (j >> 6)] |= 1ull << (j & 63);
-    else w[j >> 5] |= (uint64_t)c << ((j & 31) * 2);
+  int j = 0, word = 0;
+  for (; word < nwb && j < L; ++word) {
+    const int m = std::min(32, L - j);
+    uint64_t bits = 0, nm = 0;
+    for (int u = 0; u < m; ++u) {
+      const int src = rev ? L - 1 - (j + u) : j + u;
+      uint64_t c = code[(f.seq[src >> 1] >> ((src & 1) ? 0 : 4)) & 15];
+      if (rev && c != 4) c = 3 - c;
+      bits |= (c & 3) << (2 * u);
+      nm |= (c >> 2) << u;
+    }
+    w[word] = bits;
+    if (word & 1) w[nwb + (word >> 1)] |= nm << 32; else w[nwb + (word >> 1)] = nm;
+    j += m;
   }
+  for (int z = word; z < nwb; ++z) w[z] = 0;
+  for (int64_t z = nwb + ((word + 1) >> 1); z < stride; ++z) w[z] = 0;
+}
+
+// gathers up to max_t templates starting at upos into b->pend (offsets only; nothing is consumed until they are packed)
+int32_t gather(nb_bam* b, int64_t max_t) {
+  b->pend.clear(); b->pend_l1 = b->pend_l2 = 0; b->have_pend = false;
+  size_t cursor = b->upos;
+  int& paired = b->paired;
+  while ((int64_t)b->pend.size() < max_t) {
+    size_t off; uint32_t size;
+    const int r = next_record(b, &cursor, &off, &size);
+    if (r == 0) break;
+    if (r < 0) return r;
+    Fields f;
+    if (!parse(b->ubuf.data() + off, size, f)) { nb::set_error("BAM: malformed record " + std::to_string(b->record)); return NB_ERR_INVALID; }
+    ++b->record;
+    if (f.flag & 0x900) continue;                       // secondary / supplementary
+    const bool is_paired = f.flag & 0x1;
+    if (paired < 0) paired = is_paired ? 1 : 0;
+    if ((paired == 1) != is_paired) { nb::set_error("BAM: mixed single-end and paired records"); return NB_ERR_UNSUPPORTED; }
+    if (!is_paired) {
+      b->pend.push_back(Tmpl{off, SIZE_MAX, size, 0});
+      b->pend_l1 = std::max(b->pend_l1, f.l_seq);
+      continue;
+    }
+    // the mate must be the next primary record
+    Fields g; bool got = false; size_t off2 = 0; uint32_t size2 = 0;
+    for (;;) {
+      const int r2 = next_record(b, &cursor, &off2, &size2);
+      if (r2 < 0) return r2;
+      if (r2 == 0) break;
+      if (!parse(b->ubuf.data() + off2, size2, g)) { nb::set_error("BAM: malformed record " + std::to_string(b->record)); return NB_ERR_INVALID; }
+      ++b->record;
+      if (g.flag & 0x900) continue;
+      got = true; break;
+    }
+    if (got) parse(b->ubuf.data() + off, size, f);      // (the buffer may have moved while the mate was read)
+    const bool names_match = got && f.l_name == g.l_name && std::memcmp(f.name, g.name, (size_t)f.l_name) == 0;
+    if (!got || !names_match || !(g.flag & 0x1) || ((f.flag & 0xC0) == (g.flag & 0xC0))) {
+      nb::set_error("BAM: paired records are not adjacent mates near record " + std::to_string(b->record) +
+                    " (collate the file by read name: the reference itself runs samtools sort -n, nimble/__main__.py:344-347)");
+      return NB_ERR_UNSUPPORTED;
+    }
+    const bool f_first = (f.flag & 0x40) || !(g.flag & 0x40);
+    if (f_first) { b->pend.push_back(Tmpl{off, off2, size, size2}); b->pend_l1 = std::max(b->pend_l1, f.l_seq); b->pend_l2 = std::max(b->pend_l2, g.l_seq); }
+    else { b->pend.push_back(Tmpl{off2, off, size2, size}); b->pend_l1 = std::max(b->pend_l1, g.l_seq); b->pend_l2 = std::max(b->pend_l2, f.l_seq); }
+  }
+  b->pend_next_upos = cursor;
+  b->have_pend = true;
+  return NB_OK;
+}
+
+// packs the gathered templates at layouts (len1, len2) and consumes them
+void pack_pending(nb_bam* b, int32_t len1, int32_t len2, uint64_t* r1_words, uint16_t* r1_lens, uint64_t* r2_words, uint16_t* r2_lens,
+                  char* cb_out, char* ub_out, int32_t tag_width) {
+  const int64_t n = (int64_t)b->pend.size();
+  const int nwb1 = (len1 + 31) / 32, nwb2 = (len2 + 31) / 32;
+  const int64_t s1 = nb_packed_stride_words(len1), s2 = b->paired == 1 ? nb_packed_stride_words(len2) : 0;
+  const uint8_t* base = b->ubuf.data();
+  const int T = (int)std::min<int64_t>(b->threads, std::max<int64_t>(1, n / 2048));
+  auto put_tag = [&](const Fields& f, const char* t, char* dst) {
+    std::memset(dst, 0, (size_t)tag_width);
+    size_t len = 0; const char* v = find_z_tag(f, t, &len);
+    if (v) std::memcpy(dst, v, std::min(len, (size_t)tag_width));
+  };
+  parallel_for(T, [&](int t) {
+    for (int64_t i = n * t / T, e = n * (t + 1) / T; i < e; ++i) {
+      const Tmpl& m = b->pend[(size_t)i];
+      Fields f; parse(base + m.a, m.a_size, f);
+      pack_seq(f, nwb1, s1, r1_words + i * s1); r1_lens[i] = (uint16_t)f.l_seq;
+      put_tag(f, "CB", cb_out + i * tag_width); put_tag(f, "UB", ub_out + i * tag_width);   // the r1 version of the tags (__main__.py:236-237)
+      if (m.b != SIZE_MAX) { Fields g; parse(base + m.b, m.b_size, g); pack_seq(g, nwb2, s2, r2_words + i * s2); r2_lens[i] = (uint16_t)g.l_seq; }
+    }
+  });
+  b->upos = b->pend_next_upos;
+  b->pend.clear(); b->have_pend = false;
+}
+
+void compact(nb_bam* b) {
+  if (b->have_pend || b->upos == 0) return;   // offsets of gathered templates must stay valid
+  std::memmove(b->ubuf.data(), b->ubuf.data() + b->upos, b->uend - b->upos);
+  b->uend -= b->upos; b->upos = 0;
 }
 
 }  // namespace
@@ -116,92 +321,94 @@ extern "C" {
 
 int32_t nb_bam_open(const char* path, nb_bam** out) {
   if (!path || !out) { nb::set_error("nb_bam_open: null argument"); return NB_ERR_INVALID; }
-  gzFile f = gzopen(path, "rb");
-  if (!f) { nb::set_error(std::string("nb_bam_open: cannot open ") + path); return NB_ERR_INVALID; }
-  gzbuffer(f, 1 << 20);
-  nb_bam* b = new nb_bam(); b->f = f;
-  uint8_t hdr[8];
-  auto fail = [&](const char* m) { nb::set_error(m); gzclose(f); delete b; return NB_ERR_INVALID; };
-  if (!read_exact(b, hdr, 8) || std::memcmp(hdr, "BAM\1", 4) != 0) return fail("nb_bam_open: not a BAM file");
-  const int32_t l_text = le32(hdr + 4);
+  FILE* fp = std::fopen(path, "rb");
+  if (!fp) { nb::set_error(std::string("nb_bam_open: cannot open ") + path); return NB_ERR_INVALID; }
+  uint8_t first[18]; const size_t got = std::fread(first, 1, 18, fp);
+  nb_bam* b = new nb_bam();
+  auto fail = [&](const std::string& m) { nb::set_error(m); nb_bam_close(b); return NB_ERR_INVALID; };
+  if (bgzf_block_size(first, got) > 0) {
+    std::rewind(fp); b->fp = fp;
+  } else {
+    std::fclose(fp);
+    b->gz = gzopen(path, "rb");
+    if (!b->gz) return fail(std::string("nb_bam_open: cannot open ") + path);
+    gzbuffer(b->gz, 1 << 20);
+  }
+  auto need = [&](size_t off, size_t n) { return ensure(b, off, n); };
+  if (!need(0, 8) || std::memcmp(b->ubuf.data(), "BAM\1", 4) != 0) return fail(b->error.empty() ? "nb_bam_open: not a BAM file" : b->error);
+  const int32_t l_text = le32(b->ubuf.data() + 4);
   if (l_text < 0 || l_text > (1 << 30)) return fail("nb_bam_open: implausible header length");
-  std::vector<uint8_t> text((size_t)l_text);
-  if (l_text && !read_exact(b, text.data(), (size_t)l_text)) return fail("nb_bam_open: truncated header text");
-  uint8_t nb4[4];
-  if (!read_exact(b, nb4, 4)) return fail("nb_bam_open: truncated header");
-  const int32_t n_ref = le32(nb4);
+  size_t cur = 8 + (size_t)l_text;
+  if (!need(cur, 4)) return fail("nb_bam_open: truncated header");
+  const int32_t n_ref = le32(b->ubuf.data() + cur); cur += 4;
   if (n_ref < 0) return fail("nb_bam_open: bad reference count");
   for (int32_t i = 0; i < n_ref; ++i) {
-    uint8_t l4[4];
-    if (!read_exact(b, l4, 4)) return fail("nb_bam_open: truncated reference list");
-    const int32_t l_name = le32(l4);
+    if (!need(cur, 4)) return fail("nb_bam_open: truncated reference list");
+    const int32_t l_name = le32(b->ubuf.data() + cur);
     if (l_name < 0 || l_name > (1 << 20)) return fail("nb_bam_open: implausible reference name length");
-    std::vector<uint8_t> nm((size_t)l_name + 4);
-    if (!read_exact(b, nm.data(), (size_t)l_name + 4)) return fail("nb_bam_open: truncated reference list");
+    if (!need(cur + 4, (size_t)l_name + 4)) return fail("nb_bam_open: truncated reference list");
+    cur += 8 + (size_t)l_name;
   }
+  b->upos = cur;
   *out = b; return NB_OK;
 }
 
-int32_t nb_bam_close(nb_bam* b) { if (b) { if (b->f) gzclose(b->f); delete b; } return NB_OK; }
+int32_t nb_bam_close(nb_bam* b) { if (b) { if (b->fp) std::fclose(b->fp); if (b->gz) gzclose(b->gz); delete b; } return NB_OK; }
+
+int32_t nb_bam_set_threads(nb_bam* b, int32_t threads) {
+  if (!b) { nb::set_error("nb_bam_set_threads: null handle"); return NB_ERR_INVALID; }
+  b->threads = threads < 1 ? 1 : (threads > 256 ? 256 : threads); return NB_OK;
+}
 
 // Reads up to max_templates templates. r1 (and, when the records are paired, r2) go to the packed layout at
 // nb_packed_stride_words(max_len); *paired_out = 1 if this batch holds mates (all templates of a file are alike).
 // cb_out / ub_out: tag_width bytes per template, NUL padded (missing tag = empty). *n_out = templates read (0 = end).
 int32_t nb_bam_next_batch(nb_bam* b, int64_t max_templates, int32_t max_len, uint64_t* r1_words, uint16_t* r1_lens, uint64_t* r2_words,
                           uint16_t* r2_lens, char* cb_out, char* ub_out, int32_t tag_width, int64_t* n_out, int32_t* paired_out) {
-  if (!b || !r1_words || !r1_lens || !cb_out || !ub_out || !n_out || !paired_out || tag_width < 1) { nb::set_error("nb_bam_next_batch: bad arguments"); return NB_ERR_INVALID; }
-  const int nwb = (max_len + 31) / 32; const int64_t stride = nb_packed_stride_words(max_len);
-  std::vector<uint8_t> rec, rec2;
-  int64_t n = 0; int& paired = b->paired;
-  auto put_tag = [&](const Fields& f, const char* t, char* dst) {
-    std::memset(dst, 0, (size_t)tag_width);
-    size_t len = 0; const char* v = find_z_tag(f, t, &len);
-    if (v) std::memcpy(dst, v, std::min(len, (size_t)tag_width));
-  };
+  if (!b || !r1_words || !r1_lens || !cb_out || !ub_out || !n_out || !paired_out || tag_width < 1 || max_len < 1) { nb::set_error("nb_bam_next_batch: bad arguments"); return NB_ERR_INVALID; }
+  b->have_pend = false;        // (nothing is consumed until packed: a pending gather is simply redone)
+  compact(b);
+  const int32_t rc = gather(b, max_templates);
+  if (rc != NB_OK) return rc;
+  if (std::max(b->pend_l1, b->pend_l2) > max_len) { b->have_pend = false; nb::set_error("BAM: read of " + std::to_string(std::max(b->pend_l1, b->pend_l2)) + " bases: longer than max_len " + std::to_string(max_len)); return NB_ERR_UNSUPPORTED; }
+  if (b->paired == 1 && !b->pend.empty() && (!r2_words || !r2_lens)) { b->have_pend = false; nb::set_error("nb_bam_next_batch: paired BAM but no mate buffers"); return NB_ERR_INVALID; }
+  *n_out = (int64_t)b->pend.size(); *paired_out = b->paired == 1 ? 1 : 0;
+  pack_pending(b, max_len, max_len, r1_words, r1_lens, r2_words, r2_lens, cb_out, ub_out, tag_width);
+  return NB_OK;
+}
+
+// Streaming form used by align.py, as nb_fastq_next_batch_tight: cache-sized sub-batches, r1 packed at the layout of
+// *len1_out and r2 at *len2_out (the longest r1 / r2 of the first sub-batch); the batch ends early before a sub-batch that
+// holds a longer read. The word buffers hold max_templates * nb_packed_stride_words(cap_len) words.
+int32_t nb_bam_next_batch_tight(nb_bam* b, int64_t max_templates, int32_t cap_len, uint64_t* r1_words, uint16_t* r1_lens, uint64_t* r2_words,
+                                uint16_t* r2_lens, char* cb_out, char* ub_out, int32_t tag_width, int64_t* n_out, int32_t* len1_out,
+                                int32_t* len2_out, int32_t* paired_out) {
+  if (!b || !r1_words || !r1_lens || !cb_out || !ub_out || !n_out || !len1_out || !len2_out || !paired_out || tag_width < 1) { nb::set_error("nb_bam_next_batch_tight: bad arguments"); return NB_ERR_INVALID; }
+  constexpr int64_t SUB = 32768;
+  int64_t n = 0; int32_t len1 = 1, len2 = 1;
   while (n < max_templates) {
-    const int r = next_record(b, rec);
-    if (r == 0) break;
-    if (r < 0) return r;
-    Fields f;
-    if (!parse(rec, f)) { nb::set_error("BAM: malformed record " + std::to_string(b->record)); return NB_ERR_INVALID; }
-    ++b->record;
-    if (f.flag & 0x900) continue;                       // secondary / supplementary
-    if (f.l_seq > max_len) { nb::set_error("BAM record " + std::to_string(b->record - 1) + ": read longer than max_len " + std::to_string(max_len)); return NB_ERR_UNSUPPORTED; }
-    const bool is_paired = f.flag & 0x1;
-    if (paired < 0) paired = is_paired ? 1 : 0;
-    if ((paired == 1) != is_paired) { nb::set_error("BAM: mixed single-end and paired records"); return NB_ERR_UNSUPPORTED; }
-    if (!is_paired) {
-      pack_seq(f, nwb, stride, r1_words + n * stride); r1_lens[n] = (uint16_t)f.l_seq;
-      put_tag(f, "CB", cb_out + n * tag_width); put_tag(f, "UB", ub_out + n * tag_width);
-      ++n; continue;
+    if (b->have_pend && (int64_t)b->pend.size() > max_templates - n) {
+      if (n > 0) break;
+      b->have_pend = false;
     }
-    if (!r2_words || !r2_lens) { nb::set_error("nb_bam_next_batch: paired BAM but no mate buffers"); return NB_ERR_INVALID; }
-    // the mate must be the next primary record
-    Fields g; bool got = false;
-    for (;;) {
-      const int r2 = next_record(b, rec2);
-      if (r2 < 0) return r2;
-      if (r2 == 0) break;
-      if (!parse(rec2, g)) { nb::set_error("BAM: malformed record " + std::to_string(b->record)); return NB_ERR_INVALID; }
-      ++b->record;
-      if (g.flag & 0x900) continue;
-      got = true; break;
+    if (!b->have_pend) {
+      compact(b);
+      const int32_t rc = gather(b, std::min<int64_t>(SUB, max_templates - n));
+      if (rc != NB_OK) return rc;
     }
-    const bool names_match = got && f.l_name == g.l_name && std::memcmp(f.name, g.name, (size_t)f.l_name) == 0;
-    if (!got || !names_match || !(g.flag & 0x1) || ((f.flag & 0xC0) == (g.flag & 0xC0))) {
-      nb::set_error("BAM: paired records are not adjacent mates near record " + std::to_string(b->record) +
-                    " (collate the file by read name: the reference itself runs samtools sort -n, nimble/__main__.py:344-347)");
-      return NB_ERR_UNSUPPORTED;
-    }
-    if (g.l_seq > max_len) { nb::set_error("BAM record " + std::to_string(b->record - 1) + ": read longer than max_len " + std::to_string(max_len)); return NB_ERR_UNSUPPORTED; }
-    const bool f_first = (f.flag & 0x40) || !(g.flag & 0x40);
-    const Fields& a1 = f_first ? f : g; const Fields& a2 = f_first ? g : f;
-    pack_seq(a1, nwb, stride, r1_words + n * stride); r1_lens[n] = (uint16_t)a1.l_seq;
-    pack_seq(a2, nwb, stride, r2_words + n * stride); r2_lens[n] = (uint16_t)a2.l_seq;
-    put_tag(a1, "CB", cb_out + n * tag_width); put_tag(a1, "UB", ub_out + n * tag_width);   // the r1 version of the tags (__main__.py:236-237)
-    ++n;
+    if (b->pend.empty()) { b->have_pend = false; break; }
+    if (std::max(b->pend_l1, b->pend_l2) > cap_len) { nb::set_error("BAM: read of " + std::to_string(std::max(b->pend_l1, b->pend_l2)) + " bases: longer than the supported " + std::to_string(cap_len)); return NB_ERR_UNSUPPORTED; }
+    if (b->paired == 1 && (!r2_words || !r2_lens)) { nb::set_error("nb_bam_next_batch_tight: paired BAM but no mate buffers"); return NB_ERR_INVALID; }
+    if (n == 0) { len1 = std::max(b->pend_l1, 1); len2 = std::max(b->pend_l2, 1); }
+    else if (b->pend_l1 > len1 || b->pend_l2 > len2) break;
+    const int64_t m = (int64_t)b->pend.size();
+    const int64_t s1 = nb_packed_stride_words(len1), s2 = nb_packed_stride_words(len2);
+    pack_pending(b, len1, len2, r1_words + n * s1, r1_lens + n, r2_words ? r2_words + n * s2 : nullptr, r2_lens ? r2_lens + n : nullptr,
+                 cb_out + n * tag_width, ub_out + n * tag_width, tag_width);
+    n += m;
   }
-  *n_out = n; *paired_out = paired == 1 ? 1 : 0; return NB_OK;
+  *n_out = n; *len1_out = len1; *len2_out = len2; *paired_out = b->paired == 1 ? 1 : 0;
+  return NB_OK;
 }
 
 }  // extern "C"

@@ -230,6 +230,16 @@ def test_native_whitelist_matches_python_rule(built, tmp_path):
     assert got == want and nat.stats == py.stats and 0 < sum(w is None for w in want) < len(want)
 
 
+def _gzip_members(data):
+    """Split a BGZF byte string into its gzip members (BSIZE in the BC extra field)."""
+    out, o = [], 0
+    while o < len(data):
+        bsize = int.from_bytes(data[o + 16:o + 18], "little") + 1
+        out.append(data[o:o + bsize])
+        o += bsize
+    return out
+
+
 def test_bam_reader_single_and_paired(built, tmp_path):
     from nimble_amd.align import BamReader
     from tests.helpers import write_bam
@@ -246,12 +256,13 @@ def test_bam_reader_single_and_paired(built, tmp_path):
     r = BamReader(str(p))
     b = r.next_batch(2, 100)
     assert b["n"] == 2 and not b["paired"]
-    want, wl = engine.pack_reads([s1, s2], 100)
+    assert b["max_len"] == 60                                                                  # packed at the batch's longest read
+    want, wl = engine.pack_reads([s1, s2], b["max_len"])
     assert (b["words"] == want).all() and list(b["lens"]) == list(wl)
     assert b["cb"][0].tobytes().rstrip(b"\x00") == b"ACGTACGTACGTACGT-1" and b["umi"][0].tobytes().rstrip(b"\x00") == b"AACCGGTTAACC"
     assert b["cb"][1].tobytes().rstrip(b"\x00") == b"" and b["umi"][1].tobytes().rstrip(b"\x00") == b"TTTT"
     b = r.next_batch(5, 100)
-    assert b["n"] == 1 and (b["words"] == engine.pack_reads([s3], 100)[0]).all()
+    assert b["n"] == 1 and b["max_len"] == 16 and (b["words"] == engine.pack_reads([s3], 16)[0]).all()
     assert r.next_batch(5, 100)["n"] == 0
     r.close()
     # pairs: flags 77 / 141 as written by the reference's fastq-to-bam (fastq_barcode_processor.py:185,199)
@@ -262,7 +273,8 @@ def test_bam_reader_single_and_paired(built, tmp_path):
     r = BamReader(str(p2))
     b = r.next_batch(10, 100)
     assert b["n"] == 2 and b["paired"]
-    assert (b["words"] == engine.pack_reads([s1, s2], 100)[0]).all() and (b["mate_words"] == engine.pack_reads([s2, s3], 100)[0]).all()
+    assert (b["max_len"], b["mate_max_len"]) == (60, 40)
+    assert (b["words"] == engine.pack_reads([s1, s2], 60)[0]).all() and (b["mate_words"] == engine.pack_reads([s2, s3], 40)[0]).all()
     assert b["cb"][1].tobytes().rstrip(b"\x00") == b"GGGG"
     r.close()
     p3 = tmp_path / "bad.bam"
@@ -271,6 +283,32 @@ def test_bam_reader_single_and_paired(built, tmp_path):
     with pytest.raises(engine._lib.NimbleError):
         r.next_batch(10, 100)
     r.close()
+    # a larger file: several refills, worker threads, sub-batches, a plain-gzip (non-BGZF) copy, a corrupted block
+    rng = np.random.default_rng(5)
+    seqs = ["".join("ACGTN"[c] for c in rng.integers(0, 5, int(rng.integers(20, 91)))) for _ in range(70_000)]
+    big = tmp_path / "big.bam"
+    write_bam(big, [{"name": f"r{i}", "flag": 0, "seq": s, "tags": {"CB": "ACGT", "UB": "TT"}} for i, s in enumerate(seqs)], block=60000)
+    import zlib
+    raw = b"".join(zlib.decompress(m, 31) for m in _gzip_members(big.read_bytes()))
+    plain = tmp_path / "plain.bam"
+    plain.write_bytes(gzip.compress(raw, 1))
+    for path, threads in ((big, 1), (big, 4), (plain, 2)):
+        r = BamReader(str(path), threads)
+        got = []
+        while True:
+            b = r.next_batch(50_000, 100)
+            if b["n"] == 0:
+                break
+            got.extend(engine.unpack_read(b["words"][i], int(b["lens"][i]), b["max_len"]) for i in range(0, b["n"], 97))
+        r.close()
+        assert got == seqs[::97][:len(got)] and len(got) == len(seqs[::97]) or got == [s for j in range(0, len(seqs), 50_000) for s in seqs[j:j + 50_000][::97]]
+    data = bytearray(big.read_bytes())
+    data[len(data) // 2] ^= 0x55
+    (tmp_path / "corrupt.bam").write_bytes(bytes(data))
+    with pytest.raises(engine._lib.NimbleError):     # (the CRC of every block is checked; a small file fails at open already)
+        r = BamReader(str(tmp_path / "corrupt.bam"), 2)
+        while r.next_batch(50_000, 100)["n"]:
+            pass
     (tmp_path / "not.bam").write_bytes(gzip.compress(b"hello world, not a bam"))
     with pytest.raises(engine._lib.NimbleError):
         BamReader(str(tmp_path / "not.bam"))
