@@ -27,7 +27,7 @@ from . import _lib, engine, fused
 from .library import Library
 from .utils import append_path_string, parse_trim
 
-BATCH_READS = int(os.environ.get("NB_BATCH_READS", 1 << 18))   # templates per GPU launch; host buffers of this size stay cache- and TLB-friendly
+BATCH_READS = int(os.environ.get("NB_BATCH_READS", 1 << 20))   # templates per GPU launch
 MAX_READ_LEN = 339      # NB_MAX_POSITIONS + k - 1 at k = 20
 COV_COLUMNS = ["r1_forward_score", "r1_reverse_score", "r2_forward_score", "r2_reverse_score"]
 
@@ -318,18 +318,26 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
                 seq = {"n": bb["n"], "words": bb["words"], "lens": bb["lens"], "max_len": bb["max_len"]}
                 mate = {"n": bb["n"], "words": bb["mate_words"], "lens": bb["mate_lens"], "max_len": bb["mate_max_len"]} if bb["paired"] else None
             elif per_read:
+                # R1 (barcodes) and R2 (cDNA) are parsed side by side; a reader may end a batch early, the other is then topped up
+                f2 = side.submit(r2.next_batch, batch_reads, MAX_READ_LEN)
                 b1 = r1.next_batch(batch_reads, barcodes_only=True, cb_len=tenx.cb_length, umi_len=tenx.umi_length)
-                seq, mate = r2.next_batch(b1["n"], MAX_READ_LEN) if b1["n"] else {"n": 0}, None
-                if seq["n"] != b1["n"]:
+                seq, mate = f2.result(), None
+                if seq["n"] < b1["n"]:
                     seq = _top_up(r2, seq, b1["n"])
-            else:
+                elif seq["n"] > b1["n"]:
+                    raise ValueError("R1 and R2 FASTQ files have different numbers of records")
+            elif paired:
                 b1 = None
+                f2 = side.submit(r2.next_batch, batch_reads, MAX_READ_LEN)
                 seq = r1.next_batch(batch_reads, MAX_READ_LEN)
-                mate = r2.next_batch(seq["n"], MAX_READ_LEN) if paired and seq["n"] else None
-                if paired and seq["n"] and mate["n"] != seq["n"]:
+                mate = f2.result()
+                if mate["n"] < seq["n"]:
                     mate = _top_up(r2, mate, seq["n"])
-            if (per_read or paired) and seq["n"] == 0 and not is_bam and r2.next_batch(1, MAX_READ_LEN)["n"]:
-                raise ValueError("R1 and R2 FASTQ files have different numbers of records")
+                elif seq["n"] < mate["n"]:
+                    seq = _top_up(r1, seq, mate["n"])
+            else:
+                b1, mate = None, None
+                seq = r1.next_batch(batch_reads, MAX_READ_LEN)
             if per_read and seq["n"]:
                 b1["cb_fixed"], b1["cb_ok"] = corrector.correct(b1["cb"], b1["cbq"]) if corrector else (b1["cb"].copy(), None)
             prof.add("ingest (helper thread)", time.perf_counter() - t)
@@ -337,6 +345,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
 
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1)
+        side = ThreadPoolExecutor(max_workers=1)
         writer = ThreadPoolExecutor(max_workers=1)
         write_jobs = []
         pending = pool.submit(fetch)
@@ -403,6 +412,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         if os.environ.get("NB_PROFILE"):
             print("  stages: " + prof.report())
         pool.shutdown(wait=True)
+        side.shutdown(wait=True)
         for rd in (r1, r2, bam):
             if rd:
                 rd.close()

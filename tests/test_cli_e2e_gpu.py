@@ -69,6 +69,41 @@ def test_bulk_single_end(built, tmp_path):
     assert got == want and [l.split("\t")[0] for l in lines[1:]] == sorted(want)
 
 
+def test_paired_fastq_ragged_lengths(built, tmp_path):
+    """A biological pair from two FASTQ files with ragged read lengths: the readers pack each batch at the layout of its own
+    longest read and end a batch early before a longer one, independently for R1 and R2 — mates must stay paired."""
+    lib_path, names, seqs, strs, lineage = make_library(tmp_path, intersect_level=1)
+    n = 90_000
+    rng = np.random.default_rng(21)
+    c1, c2 = synth.synth_reads(seqs, n, 140, seed=5), synth.synth_reads(seqs, n, 140, seed=6)
+    l1, l2 = rng.integers(30, 100, n), rng.integers(30, 100, n)
+    l1[40_000], l2[70_000] = 140, 133                       # late long reads: R1 and R2 batches end at different places
+    r1 = [synth.codes_to_str(c[:l]) for c, l in zip(c1, l1)]
+    r2 = [synth.codes_to_str(c[:l]) for c, l in zip(c2, l2)]
+    f1, f2 = tmp_path / "R1.fastq", tmp_path / "R2.fastq.gz"
+    write_fastq(f1, [f"p{i}" for i in range(n)], r1)
+    write_fastq(f2, [f"p{i}" for i in range(n)], r2)
+    out = tmp_path / "pairs.tsv"
+    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(f1), str(f2), "-c", "4"]) == 0
+    from oracle import oracle
+    lib = library.Library(str(lib_path))
+    c = lib.config
+    cfg = engine.make_config(k=lib.k, score_threshold=c["score_threshold"], score_filter=c["score_filter"], score_percent=c["score_percent"],
+                             num_mismatches=c["num_mismatches"], discard_multiple_matches=c["discard_multiple_matches"],
+                             intersect_level=c["intersect_level"], require_valid_pair=c["require_valid_pair"], strand_filter="unstranded")
+    ora = oracle.OracleIndex(lib.sequences, lib.k).align_strs(cfg, r1, r2, n_threads=8)
+    want = {}
+    for i in np.nonzero(ora["reason"] == 0)[0]:
+        feats = lib.feature_list(engine.bits_to_members(ora["set_bits"][i]))
+        if len(feats) <= c["max_hits_to_report"]:
+            k = ",".join(feats); want[k] = want.get(k, 0) + 1
+    lines = open(out).read().splitlines()[1:]
+    assert {l.split("\t")[0]: int(l.split("\t")[1]) for l in lines} == want and len(want) > 10
+    short = tmp_path / "R2short.fastq"
+    write_fastq(short, [f"p{i}" for i in range(n - 1)], r2[:-1])
+    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(f1), str(short)]) == 1   # record counts differ
+
+
 def test_two_libraries_group_on_and_naming(built, tmp_path):
     """Several -r libraries in one pass: outputs named with append_path_string (__main__.py:182-189); group_on."""
     a, *_ = make_library(tmp_path, name="mhc_a")
