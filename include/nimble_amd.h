@@ -120,6 +120,8 @@ int32_t nb_align_batch(nb_ctx* ctx, const nb_config* cfg, const uint64_t* d_read
 int32_t nb_classes_count(nb_ctx* ctx, int64_t* n_classes);
 /* rows_out: n_classes * words_per_row u64 (bitset over sequences); counts_out: n_classes i64 */
 int32_t nb_classes_read(nb_ctx* ctx, int64_t cap, uint64_t* rows_out, int64_t* counts_out);
+/* classes [first, first + count) only (align.py reads the classes a batch added, not the whole table) */
+int32_t nb_classes_read_range(nb_ctx* ctx, int64_t first, int64_t count, uint64_t* rows_out, int64_t* counts_out);
 int32_t nb_reasons_read(nb_ctx* ctx, int64_t* counts_out /* NB_NUM_REASONS */);
 int32_t nb_results_reset(nb_ctx* ctx, void* stream);
 /* device pointer + length of the per-class count vector (u64), for an RCCL reduce by the caller (bench.py, align.py) */
@@ -174,8 +176,18 @@ typedef struct nb_whitelist nb_whitelist;
 int32_t nb_whitelist_load(const char* path, nb_whitelist** out);
 int32_t nb_whitelist_destroy(nb_whitelist* wl);
 int64_t nb_whitelist_size(const nb_whitelist* wl);
+/* worker threads for the exact-match pass of nb_whitelist_correct (order-independent); default 1 */
+int32_t nb_whitelist_set_threads(nb_whitelist* wl, int32_t threads);
 int32_t nb_whitelist_correct(nb_whitelist* wl, const char* raw, const char* qual, int64_t n, int32_t cb_len, char* out, uint8_t* ok,
                              int64_t* stats);
+
+/* ---- class bitsets -> feature strings (host; docs/SPEC.md §5): `group_on` naming (/root/reference/nimble/types.py:18) and the
+ * feature-count filters max_hits_to_report / discard_multi_hits (types.py:19,22). Row r's distinct feature names in ascending
+ * sequence order, comma-joined, go to blob[offsets[r] .. offsets[r+1]); the same names sorted (the form `report` groups by,
+ * __main__.py:248) to sorted_blob; reasons[r] = NB_CALLED / NB_MAX_HITS / NB_MULTI_HITS. ---- */
+int32_t nb_class_features(int64_t n_rows, int32_t words, const uint64_t* rows, int32_t n_seqs, const int32_t* seq_feature,
+                          const char* const* feature_names, int32_t n_features, int32_t max_hits, int32_t multi_hits, char* blob,
+                          int64_t blob_cap, int64_t* offsets, char* sorted_blob, int64_t sorted_cap, int64_t* sorted_offsets, int32_t* reasons);
 
 /* ---- per-read TSV rows of one batch (host): replaces the Rust binary's TSV writer for barcoded input; columns
  * nimble_features, nimble_score, r1_CB, r1_UB (consumed at /root/reference/nimble/__main__.py:237-245) + the four

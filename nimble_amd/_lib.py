@@ -78,6 +78,10 @@ SIGNATURES = {
                                        ct.c_void_p, ct.c_int32, c_i64p, ct.POINTER(ct.c_int32)]),
     "nb_whitelist_load": (ct.c_int32, [ct.c_char_p, ct.POINTER(ct.c_void_p)]),
     "nb_whitelist_destroy": (ct.c_int32, [ct.c_void_p]),
+    "nb_whitelist_set_threads": (ct.c_int32, [ct.c_void_p, ct.c_int32]),
+    "nb_classes_read_range": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.c_int64, c_u64p, c_i64p]),
+    "nb_class_features": (ct.c_int32, [ct.c_int64, ct.c_int32, ct.c_void_p, ct.c_int32, ct.c_void_p, ct.POINTER(ct.c_char_p), ct.c_int32, ct.c_int32,
+                                       ct.c_int32, ct.c_void_p, ct.c_int64, ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_void_p, ct.c_void_p]),
     "nb_whitelist_size": (ct.c_int64, [ct.c_void_p]),
     "nb_whitelist_correct": (ct.c_int32, [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_int32, ct.c_void_p, ct.c_void_p, c_i64p]),
     "nb_format_tenx_rows": (ct.c_int32, [ct.c_int64, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.POINTER(ct.c_char_p), ct.c_int64, ct.c_void_p,

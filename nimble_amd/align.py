@@ -147,6 +147,12 @@ class LibraryRun:
         self.ctx.upload(self.index)
         self.out_path = out_path
         self.per_read = per_read
+        self._feature_names = sorted(set(self.lib.features))
+        fidx = {f: i for i, f in enumerate(self._feature_names)}
+        self._seq_feature = np.array([fidx[f] for f in self.lib.features], dtype=np.int32)
+        enc = [f.encode() for f in self._feature_names]
+        self._feature_names_c = (ct.c_char_p * len(enc))(*enc)
+        self._name_bytes_max = max(len(e) for e in enc)
         self.class_feature = []     # class id -> feature string, or None when a class-level filter rejects it
         self.class_reason = []
         self.class_feat_id = []     # class id -> index into feat_strings (sorted, comma-joined features), -1 if rejected
@@ -162,25 +168,23 @@ class LibraryRun:
             self.fh.write(("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n").encode())
 
     def refresh_classes(self):
-        """Map newly interned classes to feature strings; apply the feature-level filters of docs/SPEC.md §4."""
-        rows, counts = self.ctx.classes()
-        for cid in range(len(self.class_feature), rows.shape[0]):
-            feats = self.lib.feature_list(engine.bits_to_members(rows[cid]))
-            reason = 0
-            if len(feats) > self.max_hits:
-                reason = 10   # NB_MAX_HITS
-            elif self.multi_hits > 0 and len(feats) > self.multi_hits:
-                reason = 11   # NB_MULTI_HITS
-            self.class_feature.append(",".join(feats) if reason == 0 else None)
+        """Map newly interned classes to feature strings (nb_class_features: group_on naming + the feature-level filters of
+        docs/SPEC.md §4). Call with the GPU idle."""
+        known, n = len(self.class_feature), self.ctx.n_classes()
+        if n == known:
+            return
+        rows = self.ctx.class_rows(known, n - known)
+        feats, sorted_feats, reasons = engine.class_features(rows, self._seq_feature, self._feature_names_c, len(self._feature_names),
+                                                             self.max_hits, self.multi_hits, self._name_bytes_max)
+        for f, key, reason in zip(feats, sorted_feats, reasons.tolist()):
+            self.class_feature.append(f if reason == 0 else None)
             self.class_reason.append(reason)
             fid = -1
-            if reason == 0:
-                key = ",".join(sorted(feats))          # report sorts the features of a row (__main__.py:248)
+            if reason == 0:                                # report sorts the features of a row (__main__.py:248)
                 fid = self.feat_index.setdefault(key, len(self.feat_strings))
                 if fid == len(self.feat_strings):
                     self.feat_strings.append(key)
             self.class_feat_id.append(fid)
-        return rows, counts
 
     def snapshot(self):
         """(ctypes array of class feature strings, its length, longest string, class -> feature-string id) for the classes
@@ -197,7 +201,8 @@ class LibraryRun:
         if self.per_read:
             self.fh.close()
             return
-        _, counts = self.refresh_classes()
+        self.refresh_classes()
+        _, counts = self.ctx.classes()
         for cid, cnt in enumerate(counts):
             f = self.class_feature[cid]
             if f is not None and cnt:
@@ -213,9 +218,10 @@ class LibraryRun:
 class NativeWhitelist:
     """C++ whitelist corrector (csrc/nb_host.cpp); same rule as barcodes.BarcodeCorrector, batch at a time."""
 
-    def __init__(self, path):
+    def __init__(self, path, threads=1):
         self._h = ct.c_void_p()
         _lib.check(_lib.lib().nb_whitelist_load(path.encode(), ct.byref(self._h)))
+        _lib.check(_lib.lib().nb_whitelist_set_threads(self._h, int(threads)))
         self.stats = {"cb_perfect_match": 0, "cb_corrected": 0, "cb_no_correction": 0}
 
     def correct(self, cb, cbq):
@@ -301,7 +307,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
                 runs[-1].report_path = append_path_string(report_output, suffix)
         corrector = None
         if tenx is not None and tenx.whitelist:
-            corrector = NativeWhitelist(tenx.whitelist)
+            corrector = NativeWhitelist(tenx.whitelist, num_cores)
         bam = BamReader(input[0], num_cores, pinned=True) if is_bam else None
         r1 = FastqReader(input[0], num_cores, pinned=True) if not is_bam else None
         r2 = FastqReader(input[1], num_cores, pinned=True) if len(input) == 2 else None

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -22,7 +23,48 @@ struct nb_whitelist {
   std::unordered_set<std::string> set;
   std::unordered_map<std::string, std::string> cache;   // raw -> corrected ("" = no correction)
   int64_t perfect = 0, corrected = 0, none = 0;
+  // exact-match fast path: when every entry is ACGT of one length <= 32, the 2-bit codes sit in an open-addressing table;
+  // exact matches (the bulk of real data) are order-independent, so they are resolved by worker threads and only the rest
+  // walks the sequential first-sighting cache
+  int threads = 1;
+  int fast_len = 0;                 // 0 = fast path unavailable
+  std::vector<uint64_t> table;      // code + 1, 0 = empty
+  uint64_t mask = 0;
 };
+
+namespace {
+
+inline bool encode_cb(const char* s, int len, uint64_t* out) {
+  uint64_t v = 0;
+  for (int i = 0; i < len; ++i) {
+    uint64_t c;
+    switch (s[i]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: return false; }
+    v = (v << 2) | c;
+  }
+  *out = v; return true;
+}
+
+inline uint64_t mix_cb(uint64_t x) { x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; return x; }
+
+void build_fast_table(nb_whitelist* w) {
+  w->fast_len = 0;
+  if (w->set.empty()) return;
+  const size_t len = w->set.begin()->size();
+  if (len < 1 || len > 32) return;
+  std::vector<uint64_t> codes; codes.reserve(w->set.size());
+  for (const auto& s : w->set) { uint64_t c; if (s.size() != len || !encode_cb(s.data(), (int)len, &c)) return; codes.push_back(c); }
+  size_t cap = 64; while (cap < codes.size() * 4) cap <<= 1;
+  w->table.assign(cap, 0); w->mask = cap - 1;
+  for (uint64_t c : codes) { uint64_t p = mix_cb(c) & w->mask; while (w->table[p]) p = (p + 1) & w->mask; w->table[p] = c + 1; }
+  w->fast_len = (int)len;
+}
+
+inline bool fast_contains(const nb_whitelist* w, uint64_t c) {
+  uint64_t p = mix_cb(c) & w->mask;
+  for (;;) { const uint64_t v = w->table[p]; if (!v) return false; if (v == c + 1) return true; p = (p + 1) & w->mask; }
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -39,7 +81,13 @@ int32_t nb_whitelist_load(const char* path, nb_whitelist** out) {
     if (n > b) w->set.emplace(line.data() + b, n - b);
   }
   gzclose(f);
+  build_fast_table(w);
   *out = w; return NB_OK;
+}
+
+int32_t nb_whitelist_set_threads(nb_whitelist* w, int32_t threads) {
+  if (!w) { nb::set_error("nb_whitelist_set_threads: null handle"); return NB_ERR_INVALID; }
+  w->threads = threads < 1 ? 1 : (threads > 256 ? 256 : threads); return NB_OK;
 }
 
 int32_t nb_whitelist_destroy(nb_whitelist* w) { delete w; return NB_OK; }
@@ -47,12 +95,31 @@ int32_t nb_whitelist_destroy(nb_whitelist* w) { delete w; return NB_OK; }
 int64_t nb_whitelist_size(const nb_whitelist* w) { return w ? (int64_t)w->set.size() : 0; }
 
 // n raw barcodes of fixed width cb_len (+ their quality characters) -> corrected barcodes (same layout) and ok[i] = 1,
-// or ok[i] = 0 when the pair must be dropped. Sequential on purpose: the cache makes the first sighting decide.
+// or ok[i] = 0 when the pair must be dropped. Exact matches do not depend on order and are resolved in parallel; everything
+// else is sequential on purpose: the cache makes the first sighting decide.
 int32_t nb_whitelist_correct(nb_whitelist* w, const char* raw, const char* qual, int64_t n, int32_t cb_len, char* out, uint8_t* ok,
                              int64_t* stats /* perfect, corrected, none: cumulative */) {
   if (!w || !raw || !qual || !out || !ok || cb_len < 1) { nb::set_error("nb_whitelist_correct: bad arguments"); return NB_ERR_INVALID; }
+  std::vector<uint8_t> done;
+  if (w->fast_len == cb_len && n >= 4096) {
+    done.assign((size_t)n, 0);
+    const int T = (int)std::min<int64_t>(w->threads, std::max<int64_t>(1, n / 16384));
+    std::vector<int64_t> hits((size_t)T, 0);
+    auto work = [&](int t) {
+      int64_t h = 0;
+      for (int64_t i = n * t / T, e = n * (t + 1) / T; i < e; ++i) {
+        uint64_t c;
+        if (encode_cb(raw + i * cb_len, cb_len, &c) && fast_contains(w, c)) { std::memcpy(out + i * cb_len, raw + i * cb_len, (size_t)cb_len); ok[i] = 1; done[(size_t)i] = 1; ++h; }
+      }
+      hits[(size_t)t] = h;
+    };
+    if (T <= 1) work(0);
+    else { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(work, t); work(0); for (auto& x : th) x.join(); }
+    for (int64_t h : hits) w->perfect += h;
+  }
   std::string key, cand, best;
   for (int64_t i = 0; i < n; ++i) {
+    if (!done.empty() && done[(size_t)i]) continue;
     key.assign(raw + i * cb_len, (size_t)cb_len);
     auto it = w->cache.find(key);
     const std::string* res;
@@ -80,6 +147,54 @@ int32_t nb_whitelist_correct(nb_whitelist* w, const char* raw, const char* qual,
     else { ok[i] = 1; std::memcpy(out + i * cb_len, res->data(), (size_t)cb_len); if (*res == key) ++w->perfect; else ++w->corrected; }
   }
   if (stats) { stats[0] = w->perfect; stats[1] = w->corrected; stats[2] = w->none; }
+  return NB_OK;
+}
+
+// Class bitsets -> feature strings (docs/SPEC.md §5): for row r, the distinct feature names of its members in ascending
+// sequence-index order of first appearance, comma-joined, to blob/offsets; the same names sorted, comma-joined (the form
+// `report` groups by, /root/reference/nimble/__main__.py:248), to sorted_blob/sorted_offsets; reasons[r] = NB_CALLED, or
+// NB_MAX_HITS / NB_MULTI_HITS when the feature count exceeds max_hits_to_report / discard_multi_hits (> 0).
+// seq_feature[i] = index into feature_names of sequence i. Returns NB_ERR_OVERFLOW when a blob is too small.
+int32_t nb_class_features(int64_t n_rows, int32_t words, const uint64_t* rows, int32_t n_seqs, const int32_t* seq_feature,
+                          const char* const* feature_names, int32_t n_features, int32_t max_hits, int32_t multi_hits, char* blob,
+                          int64_t blob_cap, int64_t* offsets, char* sorted_blob, int64_t sorted_cap, int64_t* sorted_offsets, int32_t* reasons) {
+  if (n_rows < 0 || words < 1 || !rows || !seq_feature || !feature_names || !blob || !offsets || !sorted_blob || !sorted_offsets || !reasons ||
+      (int64_t)words * 64 < n_seqs) { nb::set_error("nb_class_features: bad arguments"); return NB_ERR_INVALID; }
+  std::vector<int32_t> feats; std::vector<uint32_t> stamp((size_t)n_features, 0); uint32_t tick = 0;
+  std::vector<size_t> name_len((size_t)n_features);
+  for (int32_t f = 0; f < n_features; ++f) name_len[(size_t)f] = std::strlen(feature_names[f]);
+  int64_t pos = 0, spos = 0;
+  auto emit = [&](char* dst, int64_t cap, int64_t& at) -> bool {
+    for (size_t t = 0; t < feats.size(); ++t) {
+      const size_t l = name_len[(size_t)feats[t]];
+      if (at + (int64_t)l + 1 > cap) return false;
+      if (t) dst[at++] = ',';
+      std::memcpy(dst + at, feature_names[feats[t]], l); at += (int64_t)l;
+    }
+    return true;
+  };
+  for (int64_t r = 0; r < n_rows; ++r) {
+    feats.clear(); ++tick;
+    if (tick == 0) { std::fill(stamp.begin(), stamp.end(), 0u); tick = 1; }
+    const uint64_t* row = rows + r * words;
+    for (int32_t w = 0; w < words; ++w) {
+      uint64_t m = row[w];
+      while (m) {
+        const int bit = __builtin_ctzll(m); m &= m - 1;
+        const int64_t seq = (int64_t)w * 64 + bit;
+        if (seq >= n_seqs) { nb::set_error("nb_class_features: class row has a bit beyond n_seqs"); return NB_ERR_INVALID; }
+        const int32_t f = seq_feature[seq];
+        if (f < 0 || f >= n_features) { nb::set_error("nb_class_features: feature id out of range"); return NB_ERR_INVALID; }
+        if (stamp[(size_t)f] != tick) { stamp[(size_t)f] = tick; feats.push_back(f); }
+      }
+    }
+    reasons[r] = (int64_t)feats.size() > max_hits ? NB_MAX_HITS : ((multi_hits > 0 && (int64_t)feats.size() > multi_hits) ? NB_MULTI_HITS : NB_CALLED);
+    offsets[r] = pos; sorted_offsets[r] = spos;
+    if (!emit(blob, blob_cap, pos)) { nb::set_error("nb_class_features: blob too small"); return NB_ERR_OVERFLOW; }
+    std::sort(feats.begin(), feats.end(), [&](int32_t a, int32_t b) { return std::strcmp(feature_names[a], feature_names[b]) < 0; });
+    if (!emit(sorted_blob, sorted_cap, spos)) { nb::set_error("nb_class_features: blob too small"); return NB_ERR_OVERFLOW; }
+  }
+  offsets[n_rows] = pos; sorted_offsets[n_rows] = spos;
   return NB_OK;
 }
 

@@ -1360,6 +1360,15 @@ int32_t nb_classes_read(nb_ctx* c, int64_t cap, uint64_t* rows, int64_t* counts)
   return NB_OK;
 }
 
+int32_t nb_classes_read_range(nb_ctx* c, int64_t first, int64_t count, uint64_t* rows, int64_t* counts) {
+  int64_t n = 0; const int rc = nb_classes_count(c, &n); if (rc != NB_OK) return rc;
+  if (first < 0 || count < 0 || first + count > n) { set_error("nb_classes_read_range: range outside the known classes"); return NB_ERR_INVALID; }
+  if (count == 0) return NB_OK;
+  if (rows) NB_HIP(hipMemcpy(rows, c->ct.rows + (size_t)first * (size_t)c->W, (size_t)count * (size_t)c->W * 8, hipMemcpyDeviceToHost));
+  if (counts) NB_HIP(hipMemcpy(counts, c->ct.counts + first, (size_t)count * 8, hipMemcpyDeviceToHost));
+  return NB_OK;
+}
+
 int32_t nb_reasons_read(nb_ctx* c, int64_t* out) {
   if (!c || !out) { set_error("nb_reasons_read: null argument"); return NB_ERR_INVALID; }
   NB_HIP(hipSetDevice(c->device));

@@ -102,6 +102,20 @@ class Index:
             pass
 
 
+def class_features(rows, seq_feature, feature_names_c, n_features, max_hits, multi_hits, name_bytes_max):
+    """nb_class_features over a block of class rows -> (feature strings, sorted feature strings, reasons[n] i32)."""
+    n, words = rows.shape
+    cap = n * 16 + int(np.unpackbits(rows.view(np.uint8)).sum()) * (name_bytes_max + 1)     # every member could name its own feature
+    blob, sblob = np.empty(cap, dtype=np.uint8), np.empty(cap, dtype=np.uint8)
+    off, soff = np.empty(n + 1, dtype=np.int64), np.empty(n + 1, dtype=np.int64)
+    reasons = np.empty(n, dtype=np.int32)
+    check(_lib.lib().nb_class_features(n, words, rows.ctypes.data, len(seq_feature), seq_feature.ctypes.data, feature_names_c, n_features, int(max_hits),
+                                       int(multi_hits), blob.ctypes.data, cap, off.ctypes.data, sblob.ctypes.data, cap, soff.ctypes.data,
+                                       reasons.ctypes.data))
+    raw, sraw = blob.tobytes(), sblob.tobytes()
+    return ([raw[off[i]:off[i + 1]].decode() for i in range(n)], [sraw[soff[i]:soff[i + 1]].decode() for i in range(n)], reasons)
+
+
 def bits_to_members(row):
     """u64 bitset row -> sorted list of sequence indices."""
     row = np.ascontiguousarray(row, dtype=np.uint64)
@@ -154,6 +168,18 @@ class Context:
         if n.value:
             check(_lib.lib().nb_classes_read(self._h, n.value, rows.ctypes.data_as(_lib.c_u64p), counts.ctypes.data_as(_lib.c_i64p)))
         return rows, counts
+
+    def n_classes(self):
+        n = ct.c_int64()
+        check(_lib.lib().nb_classes_count(self._h, ct.byref(n)))
+        return n.value
+
+    def class_rows(self, first, count):
+        """rows[count, W] u64 of classes first .. first + count - 1."""
+        rows = np.zeros((count, self.index.words), dtype=np.uint64)
+        if count:
+            check(_lib.lib().nb_classes_read_range(self._h, int(first), int(count), rows.ctypes.data_as(_lib.c_u64p), None))
+        return rows
 
     def reasons(self):
         out = np.zeros(len(REASONS), dtype=np.int64)

@@ -24,6 +24,37 @@ def write_fastq(path, codes, prefix):
             f.write(b"".join(b"@%s%d\n%s\n+\n%s\n" % (prefix, i, seqs[i].tobytes(), q) for i in range(lo, hi)))
 
 
+def write_bam_fixed(path, codes, cells, umis):
+    """Unaligned single-end BAM with CB:Z / UB:Z tags, fixed-width records assembled with numpy, BGZF blocks of 60 KB."""
+    import struct
+    import zlib
+    n, L = codes.shape
+    nib = np.array([1, 2, 4, 8, 15], dtype=np.uint8)[codes]                # A C G T N -> BAM 4-bit codes
+    if L & 1:
+        nib = np.concatenate([nib, np.zeros((n, 1), np.uint8)], axis=1)
+    seq = (nib[:, 0::2] << 4) | nib[:, 1::2]
+    name = np.frombuffer(b"".join(b"r%09d\x00" % i for i in range(n)), dtype=np.uint8).reshape(n, 11)
+    cb = np.concatenate([np.tile(np.frombuffer(b"CBZ", np.uint8), (n, 1)), synth.BASES[cells], np.tile(np.frombuffer(b"-1\x00", np.uint8), (n, 1))], axis=1)
+    ub = np.concatenate([np.tile(np.frombuffer(b"UBZ", np.uint8), (n, 1)), synth.BASES[umis], np.zeros((n, 1), np.uint8)], axis=1)
+    body = struct.pack("<iiBBHHHIiii", -1, -1, 11, 0, 4680, 0, 4, L, -1, -1, 0)
+    size = 32 + 11 + seq.shape[1] + L + cb.shape[1] + ub.shape[1]
+    fixed = np.tile(np.frombuffer(struct.pack("<i", size) + body, np.uint8), (n, 1))
+    recs = np.concatenate([fixed, name, seq, np.full((n, L), 30, np.uint8), cb, ub], axis=1)
+    text = b"@HD\tVN:1.6\tSO:unsorted\n"
+    raw = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 0) + recs.tobytes()
+    with open(path, "wb") as f:
+        for i in range(0, len(raw) + 1, 60000):
+            data = raw[i:i + 60000]
+            comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+            cdata = comp.compress(data) + comp.flush()
+            f.write(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(cdata) + 25) + cdata +
+                    struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+            if not data:
+                break
+        else:
+            f.write(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, 27) + b"\x03\x00" + struct.pack("<II", 0, 0))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
     cores = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
@@ -67,6 +98,16 @@ def main():
     report(out, os.path.join(d, "e2e_counts.tsv"))
     t = time.time() - t0
     print(f"[e2e] report (native): {t:.2f} s, {sum(1 for _ in open(os.path.join(d, 'e2e_counts.tsv')))} output rows")
+    # --- the reference's main single-cell route: a BAM with CB/UB tags (what fastq-to-bam / cellranger produce) ---
+    bam = os.path.join(d, "e2e.bam")
+    write_bam_fixed(bam, r2, cells, umis)
+    out_bam = os.path.join(d, "e2e_bam.tsv")
+    t0 = time.time()
+    rc = align(lib, out_bam, [bam], cores, "unstranded", "", None)
+    t = time.time() - t0
+    print(f"[e2e] BAM (CB/UB tags): rc={rc} {n} records in {t:.2f} s = {n / t / 1e6:.2f} M records/s (BAM {os.path.getsize(bam) / 1e6:.0f} MB, TSV {os.path.getsize(out_bam) / 1e6:.0f} MB)")
+    for p in (bam, out_bam):
+        os.remove(p)
     for p in (csv, lib, fq, f1, f2, wlp, out, os.path.join(d, "e2e_bulk.tsv"), os.path.join(d, "e2e_counts.tsv")):
         os.remove(p)
 

@@ -215,7 +215,7 @@ def test_native_whitelist_matches_python_rule(built, tmp_path):
     with gzip.open(p, "wt") as f:
         f.write("\n".join(wl) + "\n\n")
     raws, quals = [], []
-    for _ in range(6000):
+    for _ in range(50000):             # enough for the threaded exact-match pass of the native corrector
         c = list(wl[rng.integers(0, len(wl))])
         for _ in range(int(rng.integers(0, 3))):
             c[rng.integers(0, 8)] = "ACGTN"[rng.integers(0, 5)]
@@ -223,11 +223,37 @@ def test_native_whitelist_matches_python_rule(built, tmp_path):
     raws += raws[:500]; quals += ["".join(chr(33 + int(q)) for q in rng.integers(2, 41, 8)) for _ in range(500)]   # repeats: cache decides
     py = barcodes.BarcodeCorrector(barcodes.load_whitelist(str(p)))
     want = [py.correct(r, q) for r, q in zip(raws, quals)]
-    nat = NativeWhitelist(str(p))
+    nat = NativeWhitelist(str(p), threads=3)
     cb = np.array([list(r) for r in raws], dtype="S1"); cq = np.array([list(q) for q in quals], dtype="S1")
     out, ok = nat.correct(cb, cq)
     got = [o.tobytes().decode() if k else None for o, k in zip(out, ok)]
     assert got == want and nat.stats == py.stats and 0 < sum(w is None for w in want) < len(want)
+
+
+def test_class_features_native_matches_feature_list(built):
+    """nb_class_features == Library.feature_list + the max_hits / multi_hits rule (docs/SPEC.md §4-5), grouped names included."""
+    import ctypes as ct
+    rng = np.random.default_rng(0)
+    n_seqs = 130
+    feats = [f"L{i % 7}" if i % 3 else f"Z{i}" for i in range(n_seqs)]
+    names = sorted(set(feats))
+    idx = {f: i for i, f in enumerate(names)}
+    seq_feature = np.array([idx[f] for f in feats], dtype=np.int32)
+    enc = [f.encode() for f in names]
+    arr = (ct.c_char_p * len(enc))(*enc)
+    rows = np.zeros((400, 3), dtype=np.uint64)
+    for r in range(400):
+        for m in rng.choice(n_seqs, int(rng.integers(1, 12)), replace=False):
+            rows[r, m >> 6] |= np.uint64(1) << np.uint64(m & 63)
+    for max_hits, multi in ((4, 0), (10, 2)):
+        a, b, reasons = engine.class_features(rows, seq_feature, arr, len(names), max_hits, multi, max(len(e) for e in enc))
+        for r in range(400):
+            seen = []
+            for m in engine.bits_to_members(rows[r]):
+                if feats[m] not in seen:
+                    seen.append(feats[m])
+            want = 10 if len(seen) > max_hits else (11 if multi and len(seen) > multi else 0)
+            assert a[r] == ",".join(seen) and b[r] == ",".join(sorted(seen)) and reasons[r] == want
 
 
 def _gzip_members(data):
