@@ -163,9 +163,26 @@ class LibraryRun:
         self.fh = None
         self._snap = None
         self._row_buf = None
+        self._gz_buf = None
+        self.gz_threads = 1
         if per_read:
-            self.fh = gzip.open(out_path, "wb", compresslevel=4) if out_path.endswith(".gz") else open(out_path, "wb")
-            self.fh.write(("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n").encode())
+            self.gz = out_path.endswith(".gz")          # gzip members written by nb_gzip_members (parallel), see write_text
+            self.fh = open(out_path, "wb")
+            self.write_text(np.frombuffer(("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n").encode(), dtype=np.uint8))
+
+    def write_text(self, buf):
+        """Append TSV text (uint8 array) to the per-read output, gzip-compressed when the output name ends in .gz."""
+        if not self.gz:
+            self.fh.write(memoryview(buf))
+            return
+        n = int(buf.shape[0])
+        cap = n + (n >> 9) + 64 * ((n >> 20) + 1) + 64
+        if self._gz_buf is None or self._gz_buf.shape[0] < cap:
+            self._gz_buf = np.empty(cap, dtype=np.uint8)
+        out_len = ct.c_int64()
+        buf = np.ascontiguousarray(buf)
+        _lib.check(_lib.lib().nb_gzip_members(buf.ctypes.data, n, 4, self.gz_threads, self._gz_buf.ctypes.data, cap, ct.byref(out_len)))
+        self.fh.write(memoryview(self._gz_buf[:out_len.value]))
 
     def refresh_classes(self):
         """Map newly interned classes to feature strings (nb_class_features: group_on naming + the feature-level filters of
@@ -254,7 +271,7 @@ def _write_per_read(run, snap, cls, info_raw, cov_raw, cb, cb_ok, umi):
     _lib.check(_lib.lib().nb_format_tenx_rows(n, cls.ctypes.data, info_raw.ctypes.data, cov_raw.ctypes.data, feat_arr, n_feats,
                                               cb.ctypes.data, cb.shape[1], cb_ok.ctypes.data if cb_ok is not None else None, umi.ctypes.data,
                                               umi.shape[1], buf.ctypes.data, cap, ct.byref(out_len), ct.byref(n_rows)))
-    run.fh.write(memoryview(buf[:out_len.value]))
+    run.write_text(buf[:out_len.value])
     run.n_rows += n_rows.value
     if run.rows is not None:       # the same rows, as arrays, for the fused per-cell counting
         ok = ((info_raw >> 16) & 0xFF) == 0
@@ -300,6 +317,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         for lib in libs:
             suffix = "." + os.path.splitext(os.path.basename(lib))[0] if len(libs) > 1 else ""
             runs.append(LibraryRun(lib, append_path_string(output, suffix), strand_filter, device_id, per_read))
+            runs[-1].gz_threads = max(1, int(num_cores))
             if report_output:
                 if not per_read:
                     raise ValueError("report_output needs barcoded input (BAM or --tenx)")

@@ -198,6 +198,40 @@ int32_t nb_class_features(int64_t n_rows, int32_t words, const uint64_t* rows, i
   return NB_OK;
 }
 
+// gzip for the per-read TSV (the reference's aligner writes .gz tables for BAM input, validate_gzip at
+// /root/reference/nimble/__main__.py:35-42): the text is cut into 1 MiB pieces, each deflated as its own gzip member on a
+// worker thread; concatenated members are one valid gzip file (RFC 1952 §2.2), which gzip, pandas and nb_report_tsv read.
+int32_t nb_gzip_members(const char* in, int64_t n, int32_t level, int32_t threads, char* out, int64_t out_cap, int64_t* out_len) {
+  if ((!in && n) || n < 0 || !out || !out_len) { nb::set_error("nb_gzip_members: bad arguments"); return NB_ERR_INVALID; }
+  constexpr int64_t PIECE = (int64_t)1 << 20;
+  const int64_t pieces = (n + PIECE - 1) / PIECE;
+  std::vector<std::vector<unsigned char>> comp((size_t)pieces);
+  const int T = (int)std::min<int64_t>(threads < 1 ? 1 : threads, std::max<int64_t>(1, pieces));
+  std::vector<int> bad((size_t)T, 0);
+  auto work = [&](int t) {
+    for (int64_t p = t; p < pieces; p += T) {
+      const int64_t lo = p * PIECE, len = std::min(PIECE, n - lo);
+      z_stream z; std::memset(&z, 0, sizeof z);
+      if (deflateInit2(&z, level, Z_DEFLATED, 31, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[(size_t)t] = 1; return; }
+      auto& v = comp[(size_t)p]; v.resize((size_t)deflateBound(&z, (uLong)len));
+      z.next_in = (Bytef*)(in + lo); z.avail_in = (uInt)len; z.next_out = v.data(); z.avail_out = (uInt)v.size();
+      const int rc = deflate(&z, Z_FINISH);
+      if (rc != Z_STREAM_END) { deflateEnd(&z); bad[(size_t)t] = 1; return; }
+      v.resize((size_t)z.total_out);
+      deflateEnd(&z);
+    }
+  };
+  if (T <= 1) work(0);
+  else { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(work, t); work(0); for (auto& x : th) x.join(); }
+  for (int b : bad) if (b) { nb::set_error("nb_gzip_members: deflate failed"); return NB_ERR_INVALID; }
+  int64_t pos = 0;
+  for (auto& v : comp) {
+    if (pos + (int64_t)v.size() > out_cap) { nb::set_error("nb_gzip_members: output buffer too small"); return NB_ERR_OVERFLOW; }
+    std::memcpy(out + pos, v.data(), v.size()); pos += (int64_t)v.size();
+  }
+  *out_len = pos; return NB_OK;
+}
+
 // Formats the per-read rows of one batch into `out` (caller-allocated, out_cap bytes):
 //   <features>\t<mates>\t<CB>\t<UMI>\t<r1 fwd>\t<r1 rev>\t<r2 fwd>\t<r2 rev>\n
 // for every read i with reason == CALLED, a class whose feature string is non-NULL (class_feature[cls] == NULL = rejected

@@ -101,7 +101,7 @@ def main():
     # --- the reference's main single-cell route: a BAM with CB/UB tags (what fastq-to-bam / cellranger produce) ---
     bam = os.path.join(d, "e2e.bam")
     write_bam_fixed(bam, r2, cells, umis)
-    out_bam = os.path.join(d, "e2e_bam.tsv")
+    out_bam = os.path.join(d, "e2e_bam.tsv.gz")      # the reference's aligner writes a gzip table for BAM input
     t0 = time.time()
     rc = align(lib, out_bam, [bam], cores, "unstranded", "", None)
     t = time.time() - t0
