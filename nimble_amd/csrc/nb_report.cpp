@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -117,6 +118,38 @@ std::string quote_minimal(const std::string& f) {   // csv.QUOTE_MINIMAL with de
 }
 
 
+int reducer_threads() {
+  int threads = (int)std::thread::hardware_concurrency();
+  if (const char* e = std::getenv("NB_REPORT_THREADS")) threads = std::atoi(e);
+  return std::max(1, std::min(threads, 32));
+}
+
+// sorted runs on worker threads, then rounds of pairwise merges (the keys are total orders, so the result is unique)
+template <class T, class Less>
+void parallel_sort(std::vector<T>& v, int threads, Less less) {
+  const size_t n = v.size();
+  int runs = 1; while (runs * 2 <= threads && n / (size_t)(runs * 2) >= ((size_t)1 << 16)) runs *= 2;
+  if (runs == 1) { std::sort(v.begin(), v.end(), less); return; }
+  std::vector<size_t> cut((size_t)runs + 1);
+  for (int r = 0; r <= runs; ++r) cut[(size_t)r] = n * (size_t)r / (size_t)runs;
+  { std::vector<std::thread> th;
+    for (int r = 0; r < runs; ++r) th.emplace_back([&, r] { std::sort(v.begin() + (std::ptrdiff_t)cut[(size_t)r], v.begin() + (std::ptrdiff_t)cut[(size_t)r + 1], less); });
+    for (auto& x : th) x.join(); }
+  std::vector<T> tmp(n);
+  std::vector<T>* src = &v; std::vector<T>* dst = &tmp;
+  for (int width = 1; width < runs; width *= 2) {
+    std::vector<std::thread> th;
+    for (int r = 0; r < runs; r += 2 * width)
+      th.emplace_back([&, r] {
+        const size_t lo = cut[(size_t)r], mid = cut[(size_t)std::min(r + width, runs)], hi = cut[(size_t)std::min(r + 2 * width, runs)];
+        std::merge(src->begin() + (std::ptrdiff_t)lo, src->begin() + (std::ptrdiff_t)mid, src->begin() + (std::ptrdiff_t)mid, src->begin() + (std::ptrdiff_t)hi,
+                   dst->begin() + (std::ptrdiff_t)lo, less); });
+    for (auto& x : th) x.join();
+    std::swap(src, dst);
+  }
+  if (src != &v) v.swap(tmp);
+}
+
 // The reduction proper, shared by the TSV and the array entry points. recs carry RANKS: cb / feat index cb_by_rank /
 // feat_by_rank (strings in lexicographic order), umi is any key that identifies the UMI (only grouping matters: the
 // output is ordered by (cell, feature) and integer scores do not depend on summation order; for float scores the TSV
@@ -134,11 +167,12 @@ int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& c
   if (recs.empty()) return write_empty();
   Interner singles;
   // ---- groupby(cb, umi, features).sum(): keys sorted, sums in file order ----
-  std::sort(recs.begin(), recs.end(), [&](const Rec& a, const Rec& b) {
+  auto rec_less = [](const Rec& a, const Rec& b) {
     if (a.cb != b.cb) return a.cb < b.cb;
     if (a.umi != b.umi) return a.umi < b.umi;
     if (a.feat != b.feat) return a.feat < b.feat;
-    return a.seq < b.seq; });
+    return a.seq < b.seq; };
+  parallel_sort(recs, reducer_threads(), rec_less);
   struct Row { uint32_t cb; uint64_t umi; uint32_t feat; int64_t iscore; double fscore; };
   std::vector<Row> rows;
   rows.reserve(recs.size());
@@ -282,13 +316,89 @@ int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& c
   return NB_OK;
 }
 
-}  // namespace
+// ---- the TSV front end: blocks of text are parsed by worker threads with thread-local interners, then merged ----
+constexpr int32_t RETRY_WITH_INTERNED_UMIS = 1000;
 
-extern "C" {
+// 3 bits per base, first base most significant, left-aligned in 63 bits: numeric order = lexicographic order of the
+// strings (A < C < G < N < T as in ASCII; a proper prefix sorts first because the padding code is 0)
+inline bool pack_umi(const char* b, size_t n, uint64_t* out) {
+  if (n > 21) return false;
+  uint64_t v = 0;
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t c;
+    switch (b[i]) { case 'A': c = 1; break; case 'C': c = 2; break; case 'G': c = 3; break; case 'N': c = 4; break; case 'T': c = 5; break; default: return false; }
+    v |= c << (60 - 3 * i);
+  }
+  *out = v; return true;
+}
 
-// status_out[0] = 0 normal, 1 wrote the empty output ("no data"); status_out[1] = UMIs dropped for empty intersection
-int32_t nb_report_tsv(const char* input_path, const char* output_path, double threshold, int32_t disable_thresholding, int64_t* status_out) {
-  if (!input_path || !output_path || !status_out) { nb::set_error("nb_report_tsv: null argument"); return NB_ERR_INVALID; }
+struct ParseWorker {
+  Interner cbs, feats, raw_feats, umis;
+  std::vector<uint32_t> canon_of;
+  std::vector<std::string> parts;
+  std::vector<Rec> recs;                 // ids local to this worker; seq = index inside the slice
+  std::vector<size_t> slice_begin;       // recs.size() at the start of every block's slice
+  bool any_float = false, umi_unpackable = false, any_body = false;
+  int perr = 0;
+};
+
+// parses the lines of [b, e) (no header); returns 0, or -2 for a non-numeric score
+int parse_slice(ParseWorker& w, const char* b, const char* e, const int ix[4], bool pack_umis) {
+  int max_col = std::max(std::max(ix[0], ix[1]), std::max(ix[2], ix[3]));
+  while (b < e) {
+    const char* nl = (const char*)std::memchr(b, '\n', (size_t)(e - b));
+    const char* le = nl ? nl : e;
+    size_t n = (size_t)(le - b);
+    const char* line = b;
+    b = nl ? nl + 1 : e;
+    if (n && line[n - 1] == '\r') --n;
+    if (n == 0) continue;                         // pandas skips blank lines
+    w.any_body = true;
+    if (ix[0] < 0 || ix[1] < 0 || ix[2] < 0 || ix[3] < 0) { w.perr = -1; return -1; }
+    const char* fb[4] = {nullptr, nullptr, nullptr, nullptr}; size_t fn[4] = {0, 0, 0, 0};
+    size_t s = 0; int col = 0;
+    for (size_t i = 0; i <= n && col <= max_col; ++i) if (i == n || line[i] == '\t') {
+        for (int k = 0; k < 4; ++k) if (ix[k] == col) { fb[k] = line + s; fn[k] = i - s; }
+        ++col; s = i + 1; }
+    bool skip = false;
+    for (int k = 0; k < 4; ++k) if (!fb[k] || is_na(fb[k], fn[k])) skip = true;   // dropna + != '' (__main__.py:244-245)
+    if (skip) continue;
+    Rec r{};
+    if (!parse_int_strict(fb[1], fn[1], &r.iscore)) {
+      std::string tok(fb[1], fn[1]); char* end = nullptr;
+      r.fscore = std::strtod(tok.c_str(), &end);
+      if (end == tok.c_str() || *end != '\0') { w.perr = -2; return -2; }
+      w.any_float = true; r.iscore = INT64_MIN;
+    } else r.fscore = (double)r.iscore;
+    // sort the features inside the row (__main__.py:248): once per distinct raw string
+    const uint32_t raw = w.raw_feats.get(fb[0], fn[0]);
+    if (raw == w.canon_of.size()) {
+      w.parts.clear(); size_t p = 0;
+      for (size_t i = 0; i <= fn[0]; ++i) if (i == fn[0] || fb[0][i] == ',') { w.parts.emplace_back(fb[0] + p, i - p); p = i + 1; }
+      std::sort(w.parts.begin(), w.parts.end());
+      std::string joined;
+      for (size_t i = 0; i < w.parts.size(); ++i) { if (i) joined += ','; joined += w.parts[i]; }
+      w.canon_of.push_back(w.feats.get(joined));
+    }
+    r.feat = w.canon_of[raw]; r.cb = w.cbs.get(fb[2], fn[2]);
+    if (pack_umis) { if (!pack_umi(fb[3], fn[3], &r.umi)) { w.umi_unpackable = true; return 0; } }
+    else r.umi = w.umis.get(fb[3], fn[3]);
+    w.recs.push_back(r);
+  }
+  return 0;
+}
+
+template <class F>
+void run_threads(int T, F&& f) {
+  if (T <= 1) { f(0); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back([&f, t] { f(t); });
+  f(0);
+  for (auto& x : th) x.join();
+}
+
+int32_t report_tsv_pass(const char* input_path, const char* output_path, double threshold, int32_t disable_thresholding, int64_t* status_out,
+                        int threads, bool pack_umis) {
   status_out[0] = 0; status_out[1] = 0;
   // gzopen reads plain and gzip files alike: the reference's pd.read_csv infers gzip from a ".gz" name
   // (/root/reference/nimble/__main__.py:219), which is what the aligner writes for BAM input
@@ -299,86 +409,117 @@ int32_t nb_report_tsv(const char* input_path, const char* output_path, double th
     FILE* o = std::fopen(output_path, "wb"); if (!o) { nb::set_error("nb_report_tsv: cannot write output"); return NB_ERR_INVALID; }
     std::fclose(o); status_out[0] = 1; return NB_OK;
   };
-  // ---- stream lines ----
-  std::vector<char> buf(1 << 22); size_t have = 0; bool eof = false;
-  std::string line; bool header_done = false; int ix[4] = {-1, -1, -1, -1};
-  Interner cbs, umis, feats, raw_feats; std::vector<uint32_t> canon_of;
-  std::vector<Rec> recs; bool any_float = false; uint32_t seq = 0;
-  std::vector<std::string> parts;
-  auto handle_line = [&](const char* b, size_t n) -> int {
-    if (n && b[n - 1] == '\r') --n;
-    if (!header_done) {
-      header_done = true;
+  constexpr size_t BLOCK = (size_t)64 << 20;
+  std::vector<char> buf(BLOCK + (1 << 16)); size_t have = 0; bool eof = false, any_bytes = false, header_done = false;
+  int ix[4] = {-1, -1, -1, -1};
+  std::vector<ParseWorker> workers((size_t)threads);
+  size_t n_blocks = 0;
+  while (!eof) {
+    while (have < BLOCK && !eof) {
+      const int gr = gzread(in, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, (size_t)1 << 30));
+      if (gr < 0) { int e = 0; const char* m = gzerror(in, &e); nb::set_error(std::string("nb_report_tsv: gzip stream error: ") + (m ? m : "?")); gzclose(in); return NB_ERR_INVALID; }
+      if (gr == 0) eof = true;
+      any_bytes |= gr > 0; have += (size_t)gr;
+      if (have == buf.size() && !std::memchr(buf.data(), '\n', have)) buf.resize(buf.size() * 2);   // (one line longer than the block)
+    }
+    // the part that ends on a line boundary (everything at end of file)
+    size_t usable = have;
+    if (!eof) { while (usable > 0 && buf[usable - 1] != '\n') --usable; if (usable == 0) { if (have == buf.size()) buf.resize(buf.size() * 2); continue; } }
+    const char* b = buf.data(); const char* e = buf.data() + usable;
+    if (!header_done && b < e) {
+      const char* nl = (const char*)std::memchr(b, '\n', (size_t)(e - b));
+      const char* le = nl ? nl : e; size_t n = (size_t)(le - b);
+      if (n && b[n - 1] == '\r') --n;
       size_t s = 0; int col = 0;
       for (size_t i = 0; i <= n; ++i) if (i == n || b[i] == '\t') {
           const std::string name(b + s, i - s);
           static const char* const want[4] = {"nimble_features", "nimble_score", "r1_CB", "r1_UB"};
           for (int k = 0; k < 4; ++k) if (ix[k] < 0 && name == want[k]) ix[k] = col;   // first occurrence, as list.index
           ++col; s = i + 1; }
-      return 0;
+      header_done = true;
+      b = nl ? nl + 1 : e;
     }
-    if (n == 0) return 0;                       // pandas skips blank lines
-    if (ix[0] < 0 || ix[1] < 0 || ix[2] < 0 || ix[3] < 0) return -1;
-    const char* fb[4] = {nullptr, nullptr, nullptr, nullptr}; size_t fn[4] = {0, 0, 0, 0};
-    size_t s = 0; int col = 0;
-    for (size_t i = 0; i <= n; ++i) if (i == n || b[i] == '\t') {
-        for (int k = 0; k < 4; ++k) if (ix[k] == col) { fb[k] = b + s; fn[k] = i - s; }
-        ++col; s = i + 1; }
-    for (int k = 0; k < 4; ++k) if (!fb[k] || is_na(fb[k], fn[k])) return 0;   // dropna + != '' (__main__.py:244-245)
-    Rec r{}; r.seq = seq++;
-    if (!parse_int_strict(fb[1], fn[1], &r.iscore)) {
-      std::string tok(fb[1], fn[1]); char* end = nullptr;
-      r.fscore = std::strtod(tok.c_str(), &end);
-      if (end == tok.c_str() || *end != '\0') return -2;
-      any_float = true; r.iscore = INT64_MIN;
-    } else r.fscore = (double)r.iscore;
-    // sort the features inside the row (__main__.py:248): once per distinct raw string
-    const uint32_t raw = raw_feats.get(fb[0], fn[0]);
-    if (raw == canon_of.size()) {
-      parts.clear(); size_t p = 0;
-      for (size_t i = 0; i <= fn[0]; ++i) if (i == fn[0] || fb[0][i] == ',') { parts.emplace_back(fb[0] + p, i - p); p = i + 1; }
-      std::sort(parts.begin(), parts.end());
-      std::string joined;
-      for (size_t i = 0; i < parts.size(); ++i) { if (i) joined += ','; joined += parts[i]; }
-      canon_of.push_back(feats.get(joined));
+    // slices on line boundaries
+    const int T = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, (size_t)(e - b) >> 20));
+    std::vector<const char*> cut((size_t)T + 1);
+    cut[0] = b; cut[(size_t)T] = e;
+    for (int t = 1; t < T; ++t) {
+      const char* p = b + (size_t)(e - b) * (size_t)t / (size_t)T;
+      if (p < cut[(size_t)t - 1]) p = cut[(size_t)t - 1];
+      const char* nl = (const char*)std::memchr(p, '\n', (size_t)(e - p));
+      cut[(size_t)t] = nl ? nl + 1 : e;
     }
-    r.feat = canon_of[raw]; r.cb = cbs.get(fb[2], fn[2]); r.umi = umis.get(fb[3], fn[3]);
-    recs.push_back(r); return 0;
-  };
-  bool any_bytes = false, any_body = false; int perr = 0;
-  while (!eof && perr == 0) {
-    const int gr = gzread(in, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, (size_t)1 << 30));
-    const size_t got = gr > 0 ? (size_t)gr : 0;
-    if (got == 0) eof = true;
-    any_bytes |= got > 0; have += got;
-    size_t start = 0;
-    for (;;) {
-      const char* nl = (const char*)std::memchr(buf.data() + start, '\n', have - start);
-      if (!nl) break;
-      const size_t n = (size_t)(nl - (buf.data() + start));
-      if (header_done && n > 0) any_body = true;
-      perr = handle_line(buf.data() + start, n); if (perr) break;
-      start += n + 1;
-    }
-    if (eof && start < have && perr == 0) { if (header_done) any_body = true; perr = handle_line(buf.data() + start, have - start); start = have; }
-    std::memmove(buf.data(), buf.data() + start, have - start); have -= start;
-    if (have == buf.size()) buf.resize(buf.size() * 2);
+    for (auto& w : workers) w.slice_begin.push_back(w.recs.size());
+    run_threads(T, [&](int t) { parse_slice(workers[(size_t)t], cut[(size_t)t], cut[(size_t)t + 1], ix, pack_umis); });
+    ++n_blocks;
+    bool stop = false;
+    for (auto& w : workers) if (w.perr || w.umi_unpackable) stop = true;
+    if (stop) break;
+    std::memmove(buf.data(), buf.data() + usable, have - usable); have -= usable;
   }
   gzclose(in);
+  bool any_body = false, any_float = false; int perr = 0;
+  for (auto& w : workers) { any_body |= w.any_body; any_float |= w.any_float; if (w.perr && !perr) perr = w.perr; }
   if (perr == -1 && any_body) { nb::set_error("nb_report_tsv: input TSV lacks nimble_features / nimble_score / r1_CB / r1_UB"); return NB_ERR_INVALID; }
   if (perr == -2) { nb::set_error("nb_report_tsv: non-numeric nimble_score"); return NB_ERR_INVALID; }
-  if (!any_bytes || recs.empty()) return write_empty();
+  for (auto& w : workers) if (w.umi_unpackable) return RETRY_WITH_INTERNED_UMIS;
+  size_t total = 0;
+  for (auto& w : workers) { w.slice_begin.push_back(w.recs.size()); total += w.recs.size(); }
+  if (!any_bytes || total == 0) return write_empty();
 
-  // strings -> ranks (pandas sorts group keys lexicographically), then the shared reduction
-  // (the UMI order only matters for float scores, whose sums depend on the group order; integers skip that sort)
+  // ---- merge: worker-local ids -> global ranks (pandas sorts group keys lexicographically); seq = file order ----
+  Interner cbs, feats, umis;
+  std::vector<std::vector<uint32_t>> map_cb(workers.size()), map_feat(workers.size()), map_umi(workers.size());
+  for (size_t t = 0; t < workers.size(); ++t) {
+    ParseWorker& w = workers[t];
+    map_cb[t].resize(w.cbs.size()); map_feat[t].resize(w.feats.size());
+    for (uint32_t i = 0; i < w.cbs.size(); ++i) map_cb[t][i] = cbs.get(w.cbs.ptr(i), w.cbs.len(i));
+    for (uint32_t i = 0; i < w.feats.size(); ++i) map_feat[t][i] = feats.get(w.feats.ptr(i), w.feats.len(i));
+    if (!pack_umis) { map_umi[t].resize(w.umis.size()); for (uint32_t i = 0; i < w.umis.size(); ++i) map_umi[t][i] = umis.get(w.umis.ptr(i), w.umis.len(i)); }
+  }
   const std::vector<uint32_t> rcb = cbs.ranks(), rfeat = feats.ranks();
   std::vector<uint32_t> rumi;
-  if (any_float) rumi = umis.ranks();
+  if (!pack_umis && any_float) rumi = umis.ranks();      // (the UMI order only matters for float sums; packed codes are ordered already)
   std::vector<std::string> cb_by_rank(cbs.size()), feat_by_rank(feats.size());
   for (uint32_t i = 0; i < cbs.size(); ++i) cb_by_rank[rcb[i]] = cbs.str(i);
   for (uint32_t i = 0; i < feats.size(); ++i) feat_by_rank[rfeat[i]] = feats.str(i);
-  for (auto& r : recs) { r.cb = rcb[r.cb]; if (any_float) r.umi = rumi[(size_t)r.umi]; r.feat = rfeat[r.feat]; }
+  // file-order sequence numbers: blocks in order, within a block the workers' slices in order
+  std::vector<std::vector<uint64_t>> seq_base(workers.size(), std::vector<uint64_t>(n_blocks, 0));
+  uint64_t running = 0;
+  for (size_t blk = 0; blk < n_blocks; ++blk)
+    for (size_t t = 0; t < workers.size(); ++t) { seq_base[t][blk] = running; running += workers[t].slice_begin[blk + 1] - workers[t].slice_begin[blk]; }
+  if (running >= ((uint64_t)1 << 32)) { nb::set_error("nb_report_tsv: more than 2^32 rows"); return NB_ERR_UNSUPPORTED; }
+  std::vector<Rec> recs(total);
+  std::vector<size_t> out_off(workers.size() + 1, 0);
+  for (size_t t = 0; t < workers.size(); ++t) out_off[t + 1] = out_off[t] + workers[t].recs.size();
+  run_threads((int)workers.size(), [&](int ti) {
+    const size_t t = (size_t)ti; ParseWorker& w = workers[t];
+    for (size_t blk = 0; blk < n_blocks; ++blk)
+      for (size_t i = w.slice_begin[blk]; i < w.slice_begin[blk + 1]; ++i) {
+        Rec r = w.recs[i];
+        r.cb = rcb[map_cb[t][r.cb]]; r.feat = rfeat[map_feat[t][r.feat]];
+        if (!pack_umis) { const uint32_t g = map_umi[t][(size_t)r.umi]; r.umi = any_float ? rumi[g] : g; }
+        r.seq = (uint32_t)(seq_base[t][blk] + (i - w.slice_begin[blk]));
+        recs[out_off[t] + i] = r;
+      }
+    std::vector<Rec>().swap(w.recs);
+  });
   return reduce_records(recs, cb_by_rank, feat_by_rank, any_float, threshold, disable_thresholding, output_path, status_out);
+}
+
+}  // namespace
+
+extern "C" {
+
+// status_out[0] = 0 normal, 1 wrote the empty output ("no data"); status_out[1] = UMIs dropped for empty intersection
+int32_t nb_report_tsv(const char* input_path, const char* output_path, double threshold, int32_t disable_thresholding, int64_t* status_out) {
+  if (!input_path || !output_path || !status_out) { nb::set_error("nb_report_tsv: null argument"); return NB_ERR_INVALID; }
+  const int threads = reducer_threads();
+  // UMIs are first handled as packed codes (no hash table for the largest key set of the table); a UMI that cannot be
+  // packed (other letters, longer than 21) makes the whole parse start over with interned UMI strings
+  int32_t rc = report_tsv_pass(input_path, output_path, threshold, disable_thresholding, status_out, threads, true);
+  if (rc == RETRY_WITH_INTERNED_UMIS) rc = report_tsv_pass(input_path, output_path, threshold, disable_thresholding, status_out, threads, false);
+  return rc;
 }
 
 // Same reduction from arrays (no TSV): row i = (cb_ids[i] -> cb_strings, umi_keys[i], feat_ids[i] -> feat_strings with the
