@@ -53,3 +53,39 @@ def test_report_rows_equals_report_on_tsv(idx, tmp_path, built):
     o = tmp_path / "o.tsv"
     rep.report_rows(cb_ids, umi_keys, ft_ids, [int(r[1]) for r in rows], cbs, fts, str(o), c["threshold"], c["disable_thresholding"])
     assert o.read_text() == c["output"]
+
+
+@pytest.mark.parametrize("variant", ["int", "float", "odd_umis"])
+def test_native_report_threaded_equals_single_thread_and_python(variant, tmp_path, built, monkeypatch):
+    """The golden cases are too small to reach the threaded code (text slices per worker, merge of thread-local interners,
+    parallel merge sort): a 150k-row table must give byte-identical output with 1 and 7 workers and equal the Python engine.
+    'float' exercises the order-sensitive Kahan sums (UMI group order), 'odd_umis' the fallback to interned UMI strings."""
+    import numpy as np
+    rng = np.random.default_rng({"int": 1, "float": 2, "odd_umis": 3}[variant])
+    n = 150_000
+    names = [f"L{i:02d}*{j:02d}" for i in range(6) for j in range(5)]
+    feats = [",".join(rng.permutation(names)[: int(rng.integers(1, 5))]) for _ in range(300)]
+    cells = ["".join("ACGT"[c] for c in rng.integers(0, 4, 16)) for _ in range(40)]
+    alphabet = "ACGTN" if variant != "odd_umis" else "ACGTNacgt-"
+    umis = ["".join(alphabet[c] for c in rng.integers(0, len(alphabet), 10)) for _ in range(20_000)]
+    fi, ci, ui = rng.integers(0, 300, n), rng.integers(0, 40, n), rng.integers(0, 20_000, n)
+    if variant == "float":
+        scores = [f"{x:.3f}" for x in rng.random(n) * 3]
+    else:
+        scores = [str(int(x)) for x in rng.integers(1, 3, n)]
+    path = tmp_path / "big.tsv"
+    with open(path, "w") as f:
+        f.write("nimble_features\tnimble_score\tr1_CB\tr1_UB\textra\n")
+        for i in range(n):
+            f.write(f"{feats[fi[i]]}\t{scores[i]}\t{cells[ci[i]]}\t{umis[ui[i]]}\tx\n")
+            if i % 50_000 == 7:
+                f.write("\n")                                   # blank lines are skipped
+    outs = {}
+    for threads in ("1", "7"):
+        monkeypatch.setenv("NB_REPORT_THREADS", threads)
+        out = tmp_path / f"native_{threads}.tsv"
+        rep.report(str(path), str(out), engine="native")
+        outs[threads] = open(out).read()
+    assert outs["1"] == outs["7"] and len(outs["1"].splitlines()) > 1000
+    rep.report(str(path), str(tmp_path / "py.tsv"), engine="python")
+    assert open(tmp_path / "py.tsv").read() == outs["1"]
