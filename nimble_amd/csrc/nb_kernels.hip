@@ -600,7 +600,11 @@ __device__ __forceinline__ void tri_issue(const DevIndex& ix, const TriRec& rec,
     const uint64_t y = (RCW >> (2 * (2 - r))) & kmask;
     const uint64_t c = x < y ? x : y;
     q.canon[r] = c;
+#if defined(NB_ABLATE) && NB_ABLATE >= 3
+    q.bk[r] = validk ? (kmer_bucket(c, ix.hash) & 1023u) : 0u;   // timing-only build: every lookup lands in 32 KB of the table
+#else
     q.bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;
+#endif
     q.meta[r] = (validk ? 1u : 0u) | ((x != c) ? 2u : 0u) | (next_ok ? 4u : 0u) | (nextb << 3) | (prev_ok ? 32u : 0u) | (prevb << 6);
   }
   const Bucket* __restrict__ B = ix.buckets;
