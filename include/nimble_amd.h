@@ -150,6 +150,10 @@ int32_t nb_fastq_next_batch_tight(nb_fastq* fq, int64_t max_reads, int32_t cap_l
                                   int64_t* n_out, int32_t* max_len_out, char* cb_out, int32_t cb_len, char* umi_out, int32_t umi_len,
                                   char* cbqual_out);
 
+/* a whole gzip file (any number of members, CRC-32 / ISIZE verified) decoded with the engine's own inflater
+ * (csrc/nb_inflate.cpp: what reads .gz FASTQ input); NB_ERR_OVERFLOW if cap is too small */
+int32_t nb_gunzip_file(const char* path, char* out, int64_t cap, int64_t* n_out);
+
 /* ---- BAM input (host, zlib only): replaces the Rust binary's BAM decode for `--input x.bam` (__main__.py:171-175).
  * No sort is needed (the reference sorts by UR only so that its aligner sees one UMI's records together,
  * __main__.py:344-347; this engine emits one row per template and `report` groups them). r1/r2 are packed at

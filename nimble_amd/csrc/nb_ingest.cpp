@@ -5,16 +5,15 @@
 // (/root/reference/nimble/fastq_barcode_processor.py:131-141: CB = r1[:cb_len], UMI = r1[cb_len:cb_len+umi_len]).
 //
 // Three stages, sized so that the host keeps up with the GPU for as long as the storage format allows:
-//   1. a background thread per file reads (plain: read(2); gzip: zlib inflate, inherently serial per stream) into
-//      chunks, ahead of the consumer, so R1 and R2 inflate concurrently and overlap packing, the GPU and the writer;
+//   1. a background thread per file reads (plain: read(2); gzip: the table-driven inflate of nb_inflate.cpp, CRC checked —
+//      inherently serial per stream) into chunks, ahead of the consumer, so R1 and R2 inflate concurrently and overlap
+//      packing, the GPU and the writer;
 //   2. record boundaries: `threads` workers (the reference's -c/--num_cores, __main__.py:398) find the newlines of the
 //      buffered text in parallel; strict 4-line framing is verified per record ('@' and '+' lines) and any anomaly
 //      (blank lines between records, truncation) falls back to the serial line walker, which also words the errors;
 //   3. the same workers pack the sequence lines 32 bases per word through a lookup table.
 #include <fcntl.h>
 #include <unistd.h>
-#include <zlib.h>
-
 #include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
@@ -25,14 +24,17 @@
 #include <thread>
 #include <vector>
 
+#include "nb_inflate.h"
 #include "nb_internal.h"
 
 namespace {
 
 constexpr size_t CHUNK_BYTES = (size_t)8 << 20;
 constexpr size_t MAX_QUEUED_CHUNKS = 16;
+// a chunk buffer = [history space the gzip decoder writes its 32 KiB window into][payload][overshoot slack of its match copies]
+constexpr size_t CHUNK_PREFIX = nb::GzipStream::HISTORY, CHUNK_ALLOC = CHUNK_PREFIX + CHUNK_BYTES + nb::GzipStream::SLACK + 64;
 
-struct Chunk { char* p = nullptr; size_t n = 0; };
+struct Chunk { char* p = nullptr; size_t n = 0; };   // p = allocation base; the n payload bytes start at p + CHUNK_PREFIX
 
 struct CodeTable {
   uint8_t t[256];
@@ -78,7 +80,7 @@ void parallel_for(int T, F&& f) {
 struct nb_fastq {
   // source + read-ahead thread
   int fd = -1;
-  gzFile gz = nullptr;
+  nb::GzipStream* gz = nullptr;
   std::thread reader;
   std::mutex mu;
   std::condition_variable cv_data, cv_space;
@@ -106,18 +108,17 @@ struct nb_fastq {
         std::lock_guard<std::mutex> lk(mu);
         if (!spare.empty()) { c.p = spare.back(); spare.pop_back(); }
       }
-      if (!c.p) c.p = (char*)std::malloc(CHUNK_BYTES);
+      if (!c.p) c.p = (char*)std::malloc(CHUNK_ALLOC);
       std::string err;
       if (!c.p) err = "out of memory";
-      while (c.p && c.n < CHUNK_BYTES) {
-        long got;
-        if (gz) {
-          got = gzread(gz, c.p + c.n, (unsigned)(CHUNK_BYTES - c.n));
-          if (got < 0) { int e = 0; const char* m = gzerror(gz, &e); err = std::string("gzip stream error: ") + (m ? m : "?"); break; }
-        } else {
-          got = (long)::read(fd, c.p + c.n, CHUNK_BYTES - c.n);
-          if (got < 0) { err = "read error"; break; }
-        }
+      if (c.p && gz) {
+        const long got = gz->read((uint8_t*)c.p + CHUNK_PREFIX, CHUNK_BYTES);   // (may exceed CHUNK_BYTES by one match: slack)
+        if (got < 0) err = std::string("gzip stream error: ") + (gz->error ? gz->error : "?");
+        else c.n = (size_t)got;
+      }
+      while (c.p && !gz && c.n < CHUNK_BYTES) {
+        const long got = (long)::read(fd, c.p + CHUNK_PREFIX + c.n, CHUNK_BYTES - c.n);
+        if (got < 0) { err = "read error"; break; }
         if (got == 0) break;
         c.n += (size_t)got;
       }
@@ -150,7 +151,7 @@ struct nb_fastq {
       if (!nb_) { std::free(c.p); src_error = "out of memory"; eof = true; return false; }
       buf = nb_; cap = ncap;
     }
-    std::memcpy(buf + end, c.p, c.n);
+    std::memcpy(buf + end, c.p + CHUNK_PREFIX, c.n);
     end += c.n;
     { std::lock_guard<std::mutex> lk(mu); spare.push_back(c.p); }
     return true;
@@ -278,12 +279,9 @@ int32_t nb_fastq_open(const char* path, nb_fastq** out) {
   ::lseek(fd, 0, SEEK_SET);
   nb_fastq* q = new nb_fastq();
   if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-    q->gz = gzdopen(fd, "rb");
-    if (!q->gz) { ::close(fd); delete q; nb::set_error(std::string("nb_fastq_open: cannot open ") + path); return NB_ERR_INVALID; }
-    gzbuffer(q->gz, 1 << 20);
-  } else {
-    q->fd = fd;
+    q->gz = new nb::GzipStream(); q->gz->fd = fd;
   }
+  q->fd = fd;
   q->cap = (size_t)1 << 24;
   q->buf = (char*)std::malloc(q->cap);
   if (!q->buf) { nb_fastq_close(q); nb::set_error("nb_fastq_open: out of memory"); return NB_ERR_INVALID; }
@@ -300,7 +298,7 @@ int32_t nb_fastq_close(nb_fastq* q) {
   }
   for (auto& c : q->chunks) std::free(c.p);
   for (char* p : q->spare) std::free(p);
-  if (q->gz) gzclose(q->gz);
+  delete q->gz;
   if (q->fd >= 0) ::close(q->fd);
   std::free(q->buf);
   delete q;
@@ -310,6 +308,27 @@ int32_t nb_fastq_close(nb_fastq* q) {
 int32_t nb_fastq_set_threads(nb_fastq* q, int32_t threads) {
   if (!q) { nb::set_error("nb_fastq_set_threads: null handle"); return NB_ERR_INVALID; }
   q->threads = threads < 1 ? 1 : (threads > 256 ? 256 : threads); return NB_OK;
+}
+
+// Decodes a whole gzip file (any number of members) into `out` with the engine's own inflater (nb_inflate.cpp); *n_out =
+// decoded bytes. NB_ERR_OVERFLOW if cap is too small. The tests hold the inflater to zlib through this entry point.
+int32_t nb_gunzip_file(const char* path, char* out, int64_t cap, int64_t* n_out) {
+  if (!path || !out || !n_out || cap < 0) { nb::set_error("nb_gunzip_file: bad arguments"); return NB_ERR_INVALID; }
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) { nb::set_error(std::string("nb_gunzip_file: cannot open ") + path); return NB_ERR_INVALID; }
+  nb::GzipStream gz; gz.fd = fd;
+  constexpr size_t PIECE = (size_t)1 << 20;
+  std::vector<uint8_t> buf(nb::GzipStream::HISTORY + PIECE + nb::GzipStream::SLACK + 64);
+  int64_t total = 0; int32_t rc = NB_OK;
+  for (;;) {
+    const long got = gz.read(buf.data() + nb::GzipStream::HISTORY, PIECE);
+    if (got < 0) { nb::set_error(std::string("nb_gunzip_file: ") + (gz.error ? gz.error : "?")); rc = NB_ERR_INVALID; break; }
+    if (got == 0) break;
+    if (total + got > cap) { nb::set_error("nb_gunzip_file: output buffer too small"); rc = NB_ERR_OVERFLOW; break; }
+    std::memcpy(out + total, buf.data() + nb::GzipStream::HISTORY, (size_t)got); total += got;
+  }
+  ::close(fd);
+  *n_out = total; return rc;
 }
 
 // Stage 2: finds the next up-to-max_reads records. *n_out = records found (0 = end of file), *max_seq_len_out = the

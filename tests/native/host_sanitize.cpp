@@ -74,6 +74,43 @@ int main(int argc, char** argv) {
     nb_bam_close(b);
     if (total != 300) { std::printf("bam templates %lld\n", (long long)total); return 1; }
   }
+  // ---- gzip decoder: the good file, then 90 corrupted copies (must fail or succeed cleanly, never touch memory out of bounds) ----
+  {
+    const std::string gz = dir + "/t.fastq.gz";
+    FILE* f = std::fopen(gz.c_str(), "rb"); if (!f) return 1;
+    std::vector<unsigned char> good; { unsigned char tmp[65536]; size_t k; while ((k = std::fread(tmp, 1, sizeof tmp, f)) > 0) good.insert(good.end(), tmp, tmp + k); } std::fclose(f);
+    std::vector<char> out((size_t)8 << 20); int64_t n = 0;
+    if (nb_gunzip_file(gz.c_str(), out.data(), (int64_t)out.size(), &n) != NB_OK || n < 100000) { std::printf("gunzip: %s\n", nb::g.c_str()); return 1; }
+    const std::string bad = dir + "/fuzz.gz";
+    for (int it = 0; it < 90; ++it) {
+      std::vector<unsigned char> v = good;
+      const int kind = it % 3;
+      if (kind == 0) v[rng() % v.size()] ^= (unsigned char)(1u << (rng() % 8));
+      else if (kind == 1) v.resize(rng() % v.size());
+      else { const size_t a = rng() % v.size(); for (size_t j = a; j < v.size() && j < a + 1 + rng() % 40; ++j) v[j] = (unsigned char)rng(); }
+      FILE* o = std::fopen(bad.c_str(), "wb"); std::fwrite(v.data(), 1, v.size(), o); std::fclose(o);
+      (void)nb_gunzip_file(bad.c_str(), out.data(), (int64_t)out.size(), &n);
+    }
+    nb_fastq* q = nullptr; int64_t total = 0;
+    if (nb_fastq_open(gz.c_str(), &q) != NB_OK) return 1;
+    nb_fastq_set_threads(q, 3);
+    std::vector<uint64_t> w((size_t)40000 * nb_packed_stride_words(160)); std::vector<uint16_t> ln(40000);
+    for (;;) { int32_t ml = 0; if (nb_fastq_next_batch_tight(q, 40000, 160, w.data(), ln.data(), &n, &ml, nullptr, 0, nullptr, 0, nullptr) != NB_OK) { std::printf("gz fastq: %s\n", nb::g.c_str()); return 1; } if (!n) break; total += n; }
+    nb_fastq_close(q);
+    if (total != 10000) { std::printf("gz fastq: %lld records\n", (long long)total); return 1; }
+  }
+  // ---- gzip writer + class feature strings ----
+  {
+    std::string text; for (int i = 0; i < 200000; ++i) text += "L0*01,L0*02\t1\tACGTACGTACGTACGT\tAACCGGTTAACC\t91\t0\t0\t0\n";
+    std::vector<char> out(text.size() + (text.size() >> 9) + 64 * ((text.size() >> 20) + 1) + 64); int64_t ol = 0;
+    if (nb_gzip_members(text.data(), (int64_t)text.size(), 4, 3, out.data(), (int64_t)out.size(), &ol) != NB_OK) return 1;
+    FILE* o = std::fopen((dir + "/w.gz").c_str(), "wb"); std::fwrite(out.data(), 1, (size_t)ol, o); std::fclose(o);
+    std::vector<char> back(text.size() + 16); int64_t n = 0;
+    if (nb_gunzip_file((dir + "/w.gz").c_str(), back.data(), (int64_t)back.size(), &n) != NB_OK || (size_t)n != text.size() || std::memcmp(back.data(), text.data(), text.size())) { std::printf("gzip round trip failed\n"); return 1; }
+    const char* names[3] = {"A", "B*02", "C"}; int32_t sf[70]; for (int i = 0; i < 70; ++i) sf[i] = i % 3;
+    uint64_t rows[4] = {0x5ull, 0x0ull, ~0ull, 0x3Full}; char blob[256], sblob[256]; int64_t off[3], soff[3]; int32_t rs[2];
+    if (nb_class_features(2, 2, rows, 70, sf, names, 3, 2, 0, blob, 256, off, sblob, 256, soff, rs) != NB_OK || rs[0] != NB_CALLED || rs[1] != NB_MAX_HITS) return 1;
+  }
   // ---- report reducer on the TSV the Python test wrote ----
   {
     int64_t st[2];

@@ -15,7 +15,7 @@ def test_host_code_under_sanitizers(tmp_path):
     exe = tmp_path / "host_sanitize"
     csrc = os.path.join(ROOT, "nimble_amd", "csrc")
     srcs = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), os.path.join(ROOT, "oracle", "nb_oracle.cpp")] + \
-           [os.path.join(csrc, f) for f in ("nb_index.cpp", "nb_ingest.cpp", "nb_bam.cpp", "nb_report.cpp", "nb_host.cpp")]
+           [os.path.join(csrc, f) for f in ("nb_index.cpp", "nb_ingest.cpp", "nb_inflate.cpp", "nb_bam.cpp", "nb_report.cpp", "nb_host.cpp")]
     # inputs for the driver
     import json
     import numpy as np
@@ -28,6 +28,11 @@ def test_host_code_under_sanitizers(tmp_path):
         if i % 40 == 0:
             recs.append({"name": f"r{i}", "flag": 0x800, "seq": "ACGT"})
     write_bam(tmp_path / "t.bam", recs, block=211)
+    import gzip
+    with gzip.open(tmp_path / "t.fastq.gz", "wt", compresslevel=6) as f:
+        for i in range(10000):
+            L = int(rng.integers(30, 150))
+            f.write(f"@r{i}\n{''.join('ACGTN'[c] for c in rng.integers(0, 5, L))}\n+\n{''.join(chr(33 + int(q)) for q in rng.integers(2, 41, L))}\n")
     case = json.load(open(os.path.join(ROOT, "tests", "golden", "report_cases.json")))[-1]
     (tmp_path / "in.tsv").write_text(case["input"])
     (tmp_path / "wl.txt").write_text("\n".join("".join("ACGT"[c] for c in rng.integers(0, 4, 8)) for _ in range(2000)) + "\n")
