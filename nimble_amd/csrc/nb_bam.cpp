@@ -12,7 +12,7 @@
 //     collate and the reference's fastq-to-bam produce; anything else is an error, not a silent mis-pairing.
 // BGZF is a series of gzip members of <= 64 KiB, each carrying its compressed size in a 'BC' extra field (SAM spec §4.1),
 // so members inflate independently: a refill reads a run of whole blocks and inflates them on `threads` workers, each into
-// its own slice of the output (sizes come from the ISIZE trailers), with the CRC of every block checked. A gzip file
+// its own slice of the output (sizes come from the ISIZE trailers) with the decoder of nb_inflate.cpp, CRC of every block checked. A gzip file
 // that is not BGZF (one long member) falls back to zlib's serial gzread. Records are then gathered serially (a walk
 // over the block_size chain plus the mate-adjacency rule) and packed in parallel.
 #include <zlib.h>
@@ -24,6 +24,7 @@
 #include <thread>
 #include <vector>
 
+#include "nb_inflate.h"
 #include "nb_internal.h"
 
 namespace {
@@ -100,7 +101,7 @@ bool refill(nb_bam* b) {
     // top up the compressed window
     if (!b->file_eof && b->cend - b->cpos < REFILL_COMPRESSED) {
       if (b->cpos > 0) { std::memmove(b->cbuf.data(), b->cbuf.data() + b->cpos, b->cend - b->cpos); b->cend -= b->cpos; b->cpos = 0; }
-      if (b->cbuf.size() < b->cend + REFILL_COMPRESSED) b->cbuf.resize(b->cend + REFILL_COMPRESSED);
+      if (b->cbuf.size() < b->cend + REFILL_COMPRESSED + 64) b->cbuf.resize(b->cend + REFILL_COMPRESSED + 64);   // (+64: the decoder may look 16 bytes past a block)
       const size_t got = std::fread(b->cbuf.data() + b->cend, 1, REFILL_COMPRESSED, b->fp);
       if (got < REFILL_COMPRESSED) { if (std::ferror(b->fp)) { b->error = "BAM: read error"; b->eof = true; return false; } b->file_eof = true; }
       b->cend += got;
@@ -128,21 +129,22 @@ bool refill(nb_bam* b) {
     std::vector<int> bad((size_t)T, 0);
     uint8_t* ub = b->ubuf.data() + b->uend; const uint8_t* cb = b->cbuf.data();
     parallel_for(T, [&](int t) {
-      z_stream z; std::memset(&z, 0, sizeof z);
-      if (inflateInit2(&z, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
+      // each block is decoded into scratch and copied to its slice: the decoder's match copies overshoot by a few bytes,
+      // which must not touch the neighbouring slice another worker is filling
+      std::vector<uint8_t> scratch(65536 + nb::Inflater::OUT_MARGIN + 64);
+      nb::Inflater inf;
       for (size_t i = blks.size() * (size_t)t / (size_t)T, e = blks.size() * (size_t)(t + 1) / (size_t)T; i < e; ++i) {
         const Blk& k = blks[i];
         if (k.usize == 0) continue;   // (the empty end-of-file marker block)
         const size_t xlen = le16(cb + k.coff + 10), hdr = 12 + xlen;
         if (k.csize < hdr + 8) { bad[(size_t)t] = 1; break; }
-        inflateReset(&z);
-        z.next_in = (Bytef*)(cb + k.coff + hdr); z.avail_in = (uInt)(k.csize - hdr - 8);
-        z.next_out = ub + k.uoff; z.avail_out = (uInt)k.usize;
-        const int rc = inflate(&z, Z_FINISH);
-        if (rc != Z_STREAM_END || z.avail_out != 0) { bad[(size_t)t] = 1; break; }
-        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), ub + k.uoff, (uInt)k.usize) != (uint32_t)le32(cb + k.coff + k.csize - 8)) { bad[(size_t)t] = 1; break; }
+        inf.reset();
+        const uint8_t* ip = cb + k.coff + hdr; uint8_t* op = scratch.data();
+        const nb::Inflater::Status st = inf.run(&ip, cb + k.coff + k.csize - 8, true, &op, scratch.data() + k.usize + 1, scratch.data());
+        if (st != nb::Inflater::STREAM_END || (size_t)(op - scratch.data()) != k.usize) { bad[(size_t)t] = 1; break; }
+        if (nb::crc32_update((uint32_t)crc32(0L, Z_NULL, 0), scratch.data(), k.usize) != (uint32_t)le32(cb + k.coff + k.csize - 8)) { bad[(size_t)t] = 1; break; }
+        std::memcpy(ub + k.uoff, scratch.data(), k.usize);
       }
-      inflateEnd(&z);
     });
     for (int x : bad) if (x) { b->error = "BAM: corrupt BGZF block (inflate / CRC failure)"; b->eof = true; return false; }
     b->cpos = o; b->uend += utotal;

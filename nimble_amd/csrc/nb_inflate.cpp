@@ -276,6 +276,8 @@ bool clmul_usable() { return false; }
 uint32_t crc32_clmul(uint32_t crc, const uint8_t* p, size_t n) { return (uint32_t)crc32(crc, p, (uInt)n); }
 #endif
 
+}  // namespace
+
 uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
   while (n) {
     const size_t m = n < ((size_t)1 << 30) ? n : ((size_t)1 << 30);
@@ -284,8 +286,6 @@ uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
   }
   return crc;
 }
-
-}  // namespace
 
 GzipStream::GzipStream() { ibuf = (uint8_t*)std::malloc(IBUF + 64); hist = (uint8_t*)std::malloc(HISTORY); }
 GzipStream::~GzipStream() { std::free(ibuf); std::free(hist); }

@@ -50,6 +50,9 @@ struct Inflater {
   bool read_block_header(const uint8_t** in, const uint8_t* in_end);
 };
 
+// CRC-32 of gzip / BGZF (carry-less multiplication where the CPU has it, checked against zlib at first use; else zlib)
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n);
+
 // gzip container (RFC 1952) over a file descriptor: header fields, any number of concatenated members, CRC-32 and ISIZE of
 // every member verified. read() fills `payload` with up to `cap` decoded bytes (a few more may follow: see below) and
 // returns the count, 0 at the end of the file, -1 on error (`error` says what).

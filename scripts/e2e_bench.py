@@ -75,6 +75,25 @@ def main():
     rc = align(lib, os.path.join(d, "e2e_bulk.tsv"), [fq], cores, "unstranded", "", None)
     t = time.time() - t0
     print(f"[e2e] bulk single-end: rc={rc} {n} reads in {t:.2f} s = {n / t / 1e6:.2f} M reads/s (FASTQ {os.path.getsize(fq) / 1e6:.0f} MB)")
+    # --- the same reads as a gzip FASTQ (one deflate stream: inflate is serial, csrc/nb_inflate.cpp) ---
+    import subprocess
+    ngz = min(n, 4_000_000)
+    fqz = os.path.join(d, "e2e_reads_gz.fastq.gz")
+    with open(fq, "rb") as src, open(fqz, "wb") as dst:
+        head = subprocess.Popen(["gzip", "-1", "-c"], stdin=subprocess.PIPE, stdout=dst)
+        left = ngz * 4
+        for line in src:
+            head.stdin.write(line)
+            left -= 1
+            if left == 0:
+                break
+        head.stdin.close(); head.wait()
+    t0 = time.time()
+    rc = align(lib, os.path.join(d, "e2e_bulk_gz.tsv"), [fqz], cores, "unstranded", "", None)
+    t = time.time() - t0
+    print(f"[e2e] bulk single-end, gzip FASTQ: rc={rc} {ngz} reads in {t:.2f} s = {ngz / t / 1e6:.2f} M reads/s (gz {os.path.getsize(fqz) / 1e6:.0f} MB)")
+    for p in (fqz, os.path.join(d, "e2e_bulk_gz.tsv")):
+        os.remove(p)
     # --- c3-like: 10x R1 barcodes + R2 91 bp ---
     rng = np.random.default_rng(3)
     wl = rng.integers(0, 4, size=(100000, 16), dtype=np.uint8)
