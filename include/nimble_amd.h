@@ -200,8 +200,9 @@ int32_t nb_format_tenx_rows(int64_t n, const uint32_t* cls, const uint32_t* info
                             int64_t n_classes, const char* cb, int32_t cb_len, const uint8_t* cb_ok, const char* umi, int32_t umi_len,
                             char* out, int64_t out_cap, int64_t* out_len, int64_t* n_rows);
 
-/* gzip for that table (the reference's aligner writes .gz tables, validate_gzip at __main__.py:35-42): 1 MiB pieces, one gzip
- * member each, deflated on `threads` workers; the concatenation is one valid gzip file. out_cap >= n + n/512 + 64 per MiB + 64. */
+/* gzip for that table (the reference's aligner writes .gz tables, validate_gzip at __main__.py:35-42): BGZF blocks (gzip
+ * members of <= 64 KiB input with a 'BC' size field), deflated on `threads` workers; the concatenation is one valid gzip file
+ * that block-aware readers (nb_report_tsv, bgzip tools) can also inflate in parallel. out_cap >= n + n/512 + 64 per MiB + 64. */
 int32_t nb_gzip_members(const char* in, int64_t n, int32_t level, int32_t threads, char* out, int64_t out_cap, int64_t* out_len);
 
 /* ---- `nimble report` reducer (host, no GPU needed): per-read TSV -> feature<TAB>count<TAB>cell_barcode.

@@ -45,11 +45,9 @@ void parallel_for(int T, F&& f) {
 
 struct nb_bam {
   FILE* fp = nullptr;          // BGZF path
+  nb::BgzfReader bgzf;         // (block-parallel inflate, nb_inflate.cpp)
   gzFile gz = nullptr;         // fallback: plain gzip
   int threads = 1;
-  std::vector<uint8_t> cbuf;   // compressed bytes not yet inflated: [cpos, cend)
-  size_t cpos = 0, cend = 0;
-  bool file_eof = false;
   std::vector<uint8_t> ubuf;   // inflated bytes: [upos, uend) unconsumed
   size_t upos = 0, uend = 0;
   bool eof = false;
@@ -68,89 +66,22 @@ namespace {
 int32_t le32(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-constexpr size_t REFILL_COMPRESSED = (size_t)8 << 20;
-
-// size of the BGZF block starting at p (n bytes available), 0 if the header is incomplete, -1 if it is not a BGZF block
-long bgzf_block_size(const uint8_t* p, size_t n) {
-  if (n < 18) return 0;
-  if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return -1;
-  const size_t xlen = le16(p + 10);
-  if (n < 12 + xlen) return 0;
-  for (size_t o = 12; o + 4 <= 12 + xlen;) {
-    const size_t slen = le16(p + o + 2);
-    if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2) return (long)le16(p + o + 4) + 1;
-    o += 4 + slen;
-  }
-  return -1;
-}
-
 // inflate more data behind uend; false at end of file or on error (b->error set)
 bool refill(nb_bam* b) {
   if (b->eof) return false;
+  const size_t want = (size_t)32 << 20;
+  if (b->ubuf.size() < b->uend + want) b->ubuf.resize(std::max(b->ubuf.size() * 2, b->uend + want));
   if (b->gz) {
-    const size_t want = (size_t)16 << 20;
-    if (b->ubuf.size() < b->uend + want) b->ubuf.resize(b->uend + want);
     const int r = gzread(b->gz, b->ubuf.data() + b->uend, (unsigned)want);
     if (r < 0) { int e = 0; const char* m = gzerror(b->gz, &e); b->error = std::string("BAM: gzip stream error: ") + (m ? m : "?"); b->eof = true; return false; }
     if (r == 0) { b->eof = true; return false; }
     b->uend += (size_t)r; return true;
   }
-  struct Blk { size_t coff, csize, uoff, usize; };
-  std::vector<Blk> blks;
-  for (;;) {
-    // top up the compressed window
-    if (!b->file_eof && b->cend - b->cpos < REFILL_COMPRESSED) {
-      if (b->cpos > 0) { std::memmove(b->cbuf.data(), b->cbuf.data() + b->cpos, b->cend - b->cpos); b->cend -= b->cpos; b->cpos = 0; }
-      if (b->cbuf.size() < b->cend + REFILL_COMPRESSED + 64) b->cbuf.resize(b->cend + REFILL_COMPRESSED + 64);   // (+64: the decoder may look 16 bytes past a block)
-      const size_t got = std::fread(b->cbuf.data() + b->cend, 1, REFILL_COMPRESSED, b->fp);
-      if (got < REFILL_COMPRESSED) { if (std::ferror(b->fp)) { b->error = "BAM: read error"; b->eof = true; return false; } b->file_eof = true; }
-      b->cend += got;
-    }
-    size_t o = b->cpos, utotal = 0;
-    while (o < b->cend) {
-      const long bs = bgzf_block_size(b->cbuf.data() + o, b->cend - o);
-      if (bs < 0) { b->error = "BAM: corrupt BGZF block header"; b->eof = true; return false; }
-      if (bs == 0 || o + (size_t)bs > b->cend) break;
-      if (bs < 26) { b->error = "BAM: corrupt BGZF block size"; b->eof = true; return false; }
-      const size_t usize = (uint32_t)le32(b->cbuf.data() + o + (size_t)bs - 4);
-      if (usize > 65536) { b->error = "BAM: corrupt BGZF block (ISIZE > 64 KiB)"; b->eof = true; return false; }
-      blks.push_back(Blk{o, (size_t)bs, utotal, usize});
-      utotal += usize; o += (size_t)bs;
-    }
-    if (blks.empty()) {
-      if (b->file_eof) {
-        if (b->cpos < b->cend) { b->error = "BAM: truncated BGZF block"; }
-        b->eof = true; return false;
-      }
-      continue;   // not even one whole block yet: read more
-    }
-    if (b->ubuf.size() < b->uend + utotal) b->ubuf.resize(std::max(b->ubuf.size() * 2, b->uend + utotal));
-    const int T = (int)std::min<size_t>((size_t)b->threads, std::max<size_t>(1, blks.size() / 8));
-    std::vector<int> bad((size_t)T, 0);
-    uint8_t* ub = b->ubuf.data() + b->uend; const uint8_t* cb = b->cbuf.data();
-    parallel_for(T, [&](int t) {
-      // each block is decoded into scratch and copied to its slice: the decoder's match copies overshoot by a few bytes,
-      // which must not touch the neighbouring slice another worker is filling
-      std::vector<uint8_t> scratch(65536 + nb::Inflater::OUT_MARGIN + 64);
-      nb::Inflater inf;
-      for (size_t i = blks.size() * (size_t)t / (size_t)T, e = blks.size() * (size_t)(t + 1) / (size_t)T; i < e; ++i) {
-        const Blk& k = blks[i];
-        if (k.usize == 0) continue;   // (the empty end-of-file marker block)
-        const size_t xlen = le16(cb + k.coff + 10), hdr = 12 + xlen;
-        if (k.csize < hdr + 8) { bad[(size_t)t] = 1; break; }
-        inf.reset();
-        const uint8_t* ip = cb + k.coff + hdr; uint8_t* op = scratch.data();
-        const nb::Inflater::Status st = inf.run(&ip, cb + k.coff + k.csize - 8, true, &op, scratch.data() + k.usize + 1, scratch.data());
-        if (st != nb::Inflater::STREAM_END || (size_t)(op - scratch.data()) != k.usize) { bad[(size_t)t] = 1; break; }
-        if (nb::crc32_update((uint32_t)crc32(0L, Z_NULL, 0), scratch.data(), k.usize) != (uint32_t)le32(cb + k.coff + k.csize - 8)) { bad[(size_t)t] = 1; break; }
-        std::memcpy(ub + k.uoff, scratch.data(), k.usize);
-      }
-    });
-    for (int x : bad) if (x) { b->error = "BAM: corrupt BGZF block (inflate / CRC failure)"; b->eof = true; return false; }
-    b->cpos = o; b->uend += utotal;
-    if (utotal == 0) { blks.clear(); if (b->file_eof && b->cpos == b->cend) { b->eof = true; return false; } continue; }   // only empty (EOF marker) blocks
-    return true;
-  }
+  b->bgzf.threads = b->threads;
+  const long got = b->bgzf.read(b->ubuf.data() + b->uend, want);
+  if (got < 0) { b->error = std::string("BAM: ") + (b->bgzf.error ? b->bgzf.error : "BGZF error"); b->eof = true; return false; }
+  if (got == 0) { b->eof = true; return false; }
+  b->uend += (size_t)got; return true;
 }
 
 // makes [off, off + n) of ubuf valid; false when the file ends first
@@ -328,8 +259,8 @@ int32_t nb_bam_open(const char* path, nb_bam** out) {
   uint8_t first[18]; const size_t got = std::fread(first, 1, 18, fp);
   nb_bam* b = new nb_bam();
   auto fail = [&](const std::string& m) { nb::set_error(m); nb_bam_close(b); return NB_ERR_INVALID; };
-  if (bgzf_block_size(first, got) > 0) {
-    std::rewind(fp); b->fp = fp;
+  if (nb::BgzfReader::block_size(first, got) > 0) {
+    std::rewind(fp); b->fp = fp; b->bgzf.fp = fp;
   } else {
     std::fclose(fp);
     b->gz = gzopen(path, "rb");

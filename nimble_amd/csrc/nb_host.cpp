@@ -199,27 +199,36 @@ int32_t nb_class_features(int64_t n_rows, int32_t words, const uint64_t* rows, i
 }
 
 // gzip for the per-read TSV (the reference's aligner writes .gz tables for BAM input, validate_gzip at
-// /root/reference/nimble/__main__.py:35-42): the text is cut into 1 MiB pieces, each deflated as its own gzip member on a
-// worker thread; concatenated members are one valid gzip file (RFC 1952 §2.2), which gzip, pandas and nb_report_tsv read.
+// /root/reference/nimble/__main__.py:35-42): the text is cut into BGZF blocks (SAM spec §4.1: gzip members of <= 64 KiB
+// with their size in a 'BC' extra field), each deflated on a worker thread. The concatenation is one valid gzip file
+// (RFC 1952 §2.2) for gzip / pandas, and block-addressable for bgzip-aware tools and for the parallel reader of
+// nb_report_tsv.
 int32_t nb_gzip_members(const char* in, int64_t n, int32_t level, int32_t threads, char* out, int64_t out_cap, int64_t* out_len) {
   if ((!in && n) || n < 0 || !out || !out_len) { nb::set_error("nb_gzip_members: bad arguments"); return NB_ERR_INVALID; }
-  constexpr int64_t PIECE = (int64_t)1 << 20;
+  constexpr int64_t PIECE = 0xff00;
   const int64_t pieces = (n + PIECE - 1) / PIECE;
   std::vector<std::vector<unsigned char>> comp((size_t)pieces);
-  const int T = (int)std::min<int64_t>(threads < 1 ? 1 : threads, std::max<int64_t>(1, pieces));
+  const int T = (int)std::min<int64_t>(threads < 1 ? 1 : threads, std::max<int64_t>(1, pieces / 16));
   std::vector<int> bad((size_t)T, 0);
   auto work = [&](int t) {
-    for (int64_t p = t; p < pieces; p += T) {
+    z_stream z; std::memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[(size_t)t] = 1; return; }
+    for (int64_t p = pieces * t / T, e = pieces * (t + 1) / T; p < e; ++p) {
       const int64_t lo = p * PIECE, len = std::min(PIECE, n - lo);
-      z_stream z; std::memset(&z, 0, sizeof z);
-      if (deflateInit2(&z, level, Z_DEFLATED, 31, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[(size_t)t] = 1; return; }
-      auto& v = comp[(size_t)p]; v.resize((size_t)deflateBound(&z, (uLong)len));
-      z.next_in = (Bytef*)(in + lo); z.avail_in = (uInt)len; z.next_out = v.data(); z.avail_out = (uInt)v.size();
-      const int rc = deflate(&z, Z_FINISH);
-      if (rc != Z_STREAM_END) { deflateEnd(&z); bad[(size_t)t] = 1; return; }
-      v.resize((size_t)z.total_out);
-      deflateEnd(&z);
+      auto& v = comp[(size_t)p]; v.resize(18 + 65536 + 8);
+      deflateReset(&z);
+      z.next_in = (Bytef*)(in + lo); z.avail_in = (uInt)len; z.next_out = v.data() + 18; z.avail_out = 65536 - 26;
+      if (deflate(&z, Z_FINISH) != Z_STREAM_END) { bad[(size_t)t] = 1; break; }
+      const size_t clen = (size_t)z.total_out, total = 18 + clen + 8;
+      static const unsigned char head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+      std::memcpy(v.data(), head, 16);
+      v[16] = (unsigned char)((total - 1) & 0xff); v[17] = (unsigned char)((total - 1) >> 8);
+      const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(in + lo), (uInt)len);
+      unsigned char* t8 = v.data() + 18 + clen;
+      for (int j = 0; j < 4; ++j) { t8[j] = (unsigned char)(crc >> (8 * j)); t8[4 + j] = (unsigned char)((uint32_t)len >> (8 * j)); }
+      v.resize(total);
     }
+    deflateEnd(&z);
   };
   if (T <= 1) work(0);
   else { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(work, t); work(0); for (auto& x : th) x.join(); }

@@ -7,9 +7,11 @@
 #include <immintrin.h>
 #endif
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <initializer_list>
+#include <thread>
 
 namespace nb {
 
@@ -358,6 +360,86 @@ long GzipStream::read(uint8_t* payload, size_t cap) {
     std::memmove(hist, op - keep, keep); hist_len = keep;
   } else hist_len = 0;
   return (long)(op - payload);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t REFILL_COMPRESSED = (size_t)8 << 20;
+inline uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+}  // namespace
+
+long BgzfReader::block_size(const uint8_t* p, size_t n) {
+  if (n < 18) return 0;
+  if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return -1;
+  const size_t xlen = rd16(p + 10);
+  if (n < 12 + xlen) return 0;
+  for (size_t o = 12; o + 4 <= 12 + xlen;) {
+    const size_t slen = rd16(p + o + 2);
+    if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2) return (long)rd16(p + o + 4) + 1;
+    o += 4 + slen;
+  }
+  return -1;
+}
+
+long BgzfReader::read(uint8_t* dst, size_t cap) {
+  if (cap < 65536) { error = "BGZF: output window smaller than a block"; return -1; }
+  struct Blk { size_t coff, csize, uoff, usize; };
+  std::vector<Blk> blks;
+  for (;;) {
+    if (!file_eof && cend - cpos < REFILL_COMPRESSED) {   // top up the compressed window
+      if (cpos > 0) { std::memmove(cbuf.data(), cbuf.data() + cpos, cend - cpos); cend -= cpos; cpos = 0; }
+      if (cbuf.size() < cend + REFILL_COMPRESSED + 64) cbuf.resize(cend + REFILL_COMPRESSED + 64);   // (+64: the decoder may look 16 bytes past a block)
+      const size_t got = std::fread(cbuf.data() + cend, 1, REFILL_COMPRESSED, fp);
+      if (got < REFILL_COMPRESSED) { if (std::ferror(fp)) { error = "BGZF: read error"; return -1; } file_eof = true; }
+      cend += got;
+    }
+    size_t o = cpos, utotal = 0;
+    blks.clear();
+    while (o < cend) {
+      const long bs = block_size(cbuf.data() + o, cend - o);
+      if (bs < 0) { error = "BGZF: corrupt block header"; return -1; }
+      if (bs == 0 || o + (size_t)bs > cend) break;
+      if (bs < 26) { error = "BGZF: corrupt block size"; return -1; }
+      const size_t usize = rd32(cbuf.data() + o + (size_t)bs - 4);
+      if (usize > 65536) { error = "BGZF: corrupt block (ISIZE > 64 KiB)"; return -1; }
+      if (utotal + usize > cap) break;
+      blks.push_back(Blk{o, (size_t)bs, utotal, usize});
+      utotal += usize; o += (size_t)bs;
+    }
+    if (blks.empty()) {
+      if (o == cend && file_eof) return 0;                          // clean end of file
+      if (file_eof) { error = "BGZF: truncated block"; return -1; }
+      continue;                                                     // not even one whole block yet: read more
+    }
+    const int T = (int)std::min<size_t>((size_t)(threads < 1 ? 1 : threads), std::max<size_t>(1, blks.size() / 8));
+    std::vector<int> bad((size_t)T, 0);
+    const uint8_t* cb = cbuf.data();
+    auto work = [&](int t) {
+      // each block is decoded into scratch and copied to its slice: the decoder's match copies overshoot by a few bytes,
+      // which must not touch the neighbouring slice another worker is filling
+      std::vector<uint8_t> scratch(65536 + Inflater::OUT_MARGIN + 64);
+      Inflater inf;
+      for (size_t i = blks.size() * (size_t)t / (size_t)T, e = blks.size() * (size_t)(t + 1) / (size_t)T; i < e; ++i) {
+        const Blk& k = blks[i];
+        if (k.usize == 0) continue;   // (the empty end-of-file marker block)
+        const size_t xlen = rd16(cb + k.coff + 10), hdr = 12 + xlen;
+        if (k.csize < hdr + 8) { bad[(size_t)t] = 1; break; }
+        inf.reset();
+        const uint8_t* ip = cb + k.coff + hdr; uint8_t* op = scratch.data();
+        const Inflater::Status st = inf.run(&ip, cb + k.coff + k.csize - 8, true, &op, scratch.data() + k.usize + 1, scratch.data());
+        if (st != Inflater::STREAM_END || (size_t)(op - scratch.data()) != k.usize) { bad[(size_t)t] = 1; break; }
+        if (crc32_update((uint32_t)crc32(0L, Z_NULL, 0), scratch.data(), k.usize) != rd32(cb + k.coff + k.csize - 8)) { bad[(size_t)t] = 1; break; }
+        std::memcpy(dst + k.uoff, scratch.data(), k.usize);
+      }
+    };
+    if (T <= 1) work(0);
+    else { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(work, t); work(0); for (auto& x : th) x.join(); }
+    for (int x : bad) if (x) { error = "BGZF: corrupt block (inflate / CRC failure)"; return -1; }
+    cpos = o;
+    if (utotal == 0) continue;   // only empty (end-of-file marker) blocks
+    return (long)utotal;
+  }
 }
 
 }  // namespace nb

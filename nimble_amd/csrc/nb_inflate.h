@@ -11,6 +11,8 @@
 #define NB_INFLATE_H
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <vector>
 
 namespace nb {
 
@@ -78,6 +80,25 @@ struct GzipStream {
   uint8_t* hist;                 // last <= 32 KiB of the current member's output
   size_t hist_len = 0;
   bool more_input();
+};
+
+// BGZF (SAM spec §4.1): gzip members of <= 64 KiB that carry their compressed size in a 'BC' extra field, so a run of whole
+// blocks can be cut out of the file and inflated independently on worker threads, each into its own slice of the output
+// (sizes come from the ISIZE trailers), CRC of every block checked. BAM files and the .tsv.gz tables this engine writes
+// (nb_gzip_members) have this form.
+struct BgzfReader {
+  FILE* fp = nullptr;            // owned by the caller
+  int threads = 1;
+  const char* error = nullptr;
+  // size of the BGZF block starting at p (n bytes available): 0 if the header is incomplete, -1 if it is not a BGZF block
+  static long block_size(const uint8_t* p, size_t n);
+  // decodes whole blocks into dst (cap >= 65536): returns the bytes produced, 0 at the end of the file, -1 on error
+  long read(uint8_t* dst, size_t cap);
+
+ private:
+  std::vector<uint8_t> cbuf;     // compressed bytes not yet inflated: [cpos, cend)
+  size_t cpos = 0, cend = 0;
+  bool file_eof = false;
 };
 
 }  // namespace nb

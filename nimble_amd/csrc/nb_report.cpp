@@ -9,6 +9,8 @@
 // Why native: the reference's per-UMI Python loop (utils.py:125-131,158-165) is the slow part of `report`
 // (SURVEY.md §8f item 1); this streams the TSV once and reduces 10^8-row tables in minutes instead of hours.
 // Compiled with -ffp-contract=off: no fused multiply-add may alter the double arithmetic.
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -21,6 +23,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "nb_inflate.h"
 #include "nb_internal.h"
 
 namespace {
@@ -316,6 +319,35 @@ int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& c
   return NB_OK;
 }
 
+// plain text, BGZF (block-parallel inflate: the tables this engine writes) or any other gzip file (serial inflate)
+struct TextSource {
+  int fd = -1; FILE* fp = nullptr; int kind = 0;   // 0 plain, 1 BGZF, 2 gzip
+  nb::BgzfReader bgzf; nb::GzipStream* gz = nullptr; std::vector<uint8_t> stage; const char* error = nullptr;
+  bool open(const char* path, int threads) {
+    fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    uint8_t first[18]; const long got = (long)::read(fd, first, 18);
+    ::lseek(fd, 0, SEEK_SET);
+    if (got >= 18 && nb::BgzfReader::block_size(first, (size_t)got) > 0) { kind = 1; fp = fdopen(fd, "rb"); if (!fp) return false; bgzf.fp = fp; bgzf.threads = threads; }
+    else if (got >= 2 && first[0] == 0x1f && first[1] == 0x8b) { kind = 2; gz = new nb::GzipStream(); gz->fd = fd; stage.resize(nb::GzipStream::HISTORY + ((size_t)8 << 20) + nb::GzipStream::SLACK + 64); }
+    return true;
+  }
+  // up to cap bytes (cap >= 65536) to dst; 0 at end of file, -1 on error
+  long read(char* dst, size_t cap) {
+    if (kind == 1) { const long n = bgzf.read((uint8_t*)dst, cap); if (n < 0) error = bgzf.error; return n; }
+    if (kind == 2) {
+      uint8_t* payload = stage.data() + nb::GzipStream::HISTORY;
+      const long n = gz->read(payload, std::min<size_t>(cap - 512, (size_t)8 << 20));   // (may exceed its cap by one match: < 512 bytes)
+      if (n < 0) { error = gz->error; return n; }
+      std::memcpy(dst, payload, (size_t)n); return n;
+    }
+    const long n = (long)::read(fd, dst, std::min<size_t>(cap, (size_t)1 << 30));
+    if (n < 0) error = "read error";
+    return n;
+  }
+  ~TextSource() { delete gz; if (fp) std::fclose(fp); else if (fd >= 0) ::close(fd); }
+};
+
 // ---- the TSV front end: blocks of text are parsed by worker threads with thread-local interners, then merged ----
 constexpr int32_t RETRY_WITH_INTERNED_UMIS = 1000;
 
@@ -400,11 +432,10 @@ void run_threads(int T, F&& f) {
 int32_t report_tsv_pass(const char* input_path, const char* output_path, double threshold, int32_t disable_thresholding, int64_t* status_out,
                         int threads, bool pack_umis) {
   status_out[0] = 0; status_out[1] = 0;
-  // gzopen reads plain and gzip files alike: the reference's pd.read_csv infers gzip from a ".gz" name
+  // plain and gzip files alike: the reference's pd.read_csv infers gzip from a ".gz" name
   // (/root/reference/nimble/__main__.py:219), which is what the aligner writes for BAM input
-  gzFile in = gzopen(input_path, "rb");
-  if (!in) { nb::set_error(std::string("nb_report_tsv: cannot open ") + input_path); return NB_ERR_INVALID; }
-  gzbuffer(in, 1 << 20);
+  TextSource in;
+  if (!in.open(input_path, threads)) { nb::set_error(std::string("nb_report_tsv: cannot open ") + input_path); return NB_ERR_INVALID; }
   auto write_empty = [&]() -> int32_t {
     FILE* o = std::fopen(output_path, "wb"); if (!o) { nb::set_error("nb_report_tsv: cannot write output"); return NB_ERR_INVALID; }
     std::fclose(o); status_out[0] = 1; return NB_OK;
@@ -414,17 +445,19 @@ int32_t report_tsv_pass(const char* input_path, const char* output_path, double 
   int ix[4] = {-1, -1, -1, -1};
   std::vector<ParseWorker> workers((size_t)threads);
   size_t n_blocks = 0;
+  size_t target = BLOCK;
   while (!eof) {
-    while (have < BLOCK && !eof) {
-      const int gr = gzread(in, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, (size_t)1 << 30));
-      if (gr < 0) { int e = 0; const char* m = gzerror(in, &e); nb::set_error(std::string("nb_report_tsv: gzip stream error: ") + (m ? m : "?")); gzclose(in); return NB_ERR_INVALID; }
+    while (have < target && !eof) {
+      if (buf.size() - have < 65536) buf.resize(buf.size() + BLOCK);
+      const long gr = in.read(buf.data() + have, buf.size() - have);
+      if (gr < 0) { nb::set_error(std::string("nb_report_tsv: ") + (in.error ? in.error : "read error")); return NB_ERR_INVALID; }
       if (gr == 0) eof = true;
       any_bytes |= gr > 0; have += (size_t)gr;
-      if (have == buf.size() && !std::memchr(buf.data(), '\n', have)) buf.resize(buf.size() * 2);   // (one line longer than the block)
     }
     // the part that ends on a line boundary (everything at end of file)
     size_t usable = have;
-    if (!eof) { while (usable > 0 && buf[usable - 1] != '\n') --usable; if (usable == 0) { if (have == buf.size()) buf.resize(buf.size() * 2); continue; } }
+    if (!eof) { while (usable > 0 && buf[usable - 1] != '\n') --usable; if (usable == 0) { target = have + BLOCK; continue; } }   // (one line longer than the block)
+    target = BLOCK;
     const char* b = buf.data(); const char* e = buf.data() + usable;
     if (!header_done && b < e) {
       const char* nl = (const char*)std::memchr(b, '\n', (size_t)(e - b));
@@ -457,7 +490,6 @@ int32_t report_tsv_pass(const char* input_path, const char* output_path, double 
     if (stop) break;
     std::memmove(buf.data(), buf.data() + usable, have - usable); have -= usable;
   }
-  gzclose(in);
   bool any_body = false, any_float = false; int perr = 0;
   for (auto& w : workers) { any_body |= w.any_body; any_float |= w.any_float; if (w.perr && !perr) perr = w.perr; }
   if (perr == -1 && any_body) { nb::set_error("nb_report_tsv: input TSV lacks nimble_features / nimble_score / r1_CB / r1_UB"); return NB_ERR_INVALID; }

@@ -89,3 +89,23 @@ def test_native_report_threaded_equals_single_thread_and_python(variant, tmp_pat
     assert outs["1"] == outs["7"] and len(outs["1"].splitlines()) > 1000
     rep.report(str(path), str(tmp_path / "py.tsv"), engine="python")
     assert open(tmp_path / "py.tsv").read() == outs["1"]
+    if variant == "int":
+        # the same table as the aligner writes it for BAM input: BGZF blocks (nb_gzip_members, inflated block-parallel by the
+        # reducer) and as an ordinary gzip stream (serial inflate) — same counts
+        import ctypes as ct
+        import gzip
+        import numpy as np
+        from nimble_amd import _lib
+        text = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        n = text.shape[0]
+        cap = n + (n >> 9) + 64 * ((n >> 20) + 1) + 64
+        out, out_len = np.empty(cap, dtype=np.uint8), ct.c_int64()
+        _lib.check(_lib.lib().nb_gzip_members(text.ctypes.data, n, 4, 3, out.ctypes.data, cap, ct.byref(out_len)))
+        blob = out[:out_len.value].tobytes()
+        assert gzip.decompress(blob) == text.tobytes() and blob[:4] == b"\x1f\x8b\x08\x04" and blob[12:16] == b"BC\x02\x00"
+        (tmp_path / "bgzf.tsv.gz").write_bytes(blob)
+        with gzip.open(tmp_path / "plain.tsv.gz", "wb", compresslevel=3) as f:
+            f.write(text.tobytes())
+        for name in ("bgzf.tsv.gz", "plain.tsv.gz"):
+            rep.report(str(tmp_path / name), str(tmp_path / "gz_out.tsv"), engine="native")
+            assert open(tmp_path / "gz_out.tsv").read() == outs["1"], name
