@@ -1,4 +1,6 @@
 """Seeded synthetic HLA-like libraries and reads (SURVEY.md §8d recipe). No external data; numpy PCG64 only."""
+import os
+
 import numpy as np
 
 LIB_SEED = 20260109
@@ -98,6 +100,8 @@ def synth_reads_packed_torch(seqs, n, read_len, seed, device, chunk=1 << 20, fra
     for lo in range(0, n, chunk):
         m = min(chunk, n - lo)
         allele = torch.randint(0, len(seqs), (m,), generator=g, device=device)
+        if os.environ.get("NB_SYNTH_SORTED"):          # locality experiment (profiles/r01_tuning_notes.md): reads ordered by origin
+            allele = torch.sort(allele).values
         start = (torch.rand(m, generator=g, device=device, dtype=torch.float64) * (lens[allele] - read_len + 1)).to(torch.int64)
         reads = flat[(offs[allele] + start)[:, None] + ar[None, :]]
         rev = torch.rand(m, generator=g, device=device) < 0.5
