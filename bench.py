@@ -246,7 +246,7 @@ def main():
                                       "Infinity Cache; algorithmic bytes per launch = " + str(bytes_per_read * n)) if traffic else None,
                      "kernel": engine._lib.lib().nb_kernel_name(L, args.k, len(strs), 0).decode(), "kernel_ms_avg": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_read": bytes_per_read},
-        # The ceiling this kernel actually runs into (profiles/r01_tuning_notes.md): the rate at which L2-miss requests
+        # The nearest hard memory-side ceiling (profiles/r01_tuning_notes.md; the binding constraint is instruction issue): the rate at which L2-miss requests
         # (64 B each, TCC_MISS_sum of the committed PMC pass) can be served by the fabric / Infinity Cache / HBM, measured
         # at 55-57 G requests/s on this chip (two-choice cuckoo experiment on c2; c5, whose index lives in HBM, sits there).
         "secondary_roofline": ({"bound": "l2_miss_requests", "achieved": miss_requests / avg_kernel_s / 1e9, "peak": 56.0, "unit": "G requests/s",
