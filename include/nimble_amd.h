@@ -158,7 +158,8 @@ int32_t nb_gunzip_file(const char* path, char* out, int64_t cap, int64_t* n_out)
  * No sort is needed (the reference sorts by UR only so that its aligner sees one UMI's records together,
  * __main__.py:344-347; this engine emits one row per template and `report` groups them). r1/r2 are packed at
  * nb_packed_stride_words(max_len); cb_out/ub_out receive the Z tags CB / UB of r1, tag_width bytes per template, NUL
- * padded. *paired_out = 1 when the records are adjacent mates. *n_out = templates read (0 = end of file). ---- */
+ * padded. *paired_out = 1 when the file holds pairs (mates adjacent or not: a record waits for its mate by read name; an orphan
+ * comes out with an empty partner). *n_out = templates read (0 = end of file). ---- */
 typedef struct nb_bam nb_bam;
 int32_t nb_bam_open(const char* path, nb_bam** out);
 int32_t nb_bam_close(nb_bam* bam);

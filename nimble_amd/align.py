@@ -11,7 +11,7 @@ Input modes
   * two FASTQ(.gz) + tenx options: R1 carries CB+UMI (fastq_barcode_processor.py:131-141), R2 is aligned; one row per
     called read with r1_CB / r1_UB — what the reference obtains via `fastq-to-bam` + BAM input.
   * two FASTQ(.gz) without tenx options: a biological pair (needs the paired kernel).
-  * one BAM (single-end or name-collated pairs with CB/UB tags): read with the built-in zlib BAM reader
+  * one BAM (single-end or pairs in any record order, with CB/UB tags): read with the built-in BAM reader
     (csrc/nb_bam.cpp), one row per called template; the reference's `samtools sort -t UR -n` staging (sort_input_bam,
     __main__.py:312-370) is unnecessary because `report` groups by (cell, UMI) itself, so nothing is sorted or deleted.
 """

@@ -8,8 +8,10 @@
 // tags the reference's own fastq-to-bam writes, fastq_barcode_processor.py:189-190,203-204).
 //   * secondary / supplementary records (0x100, 0x800) are skipped;
 //   * a record stored reverse-complemented (0x10) is turned back into the read as sequenced;
-//   * paired records (0x1) must be adjacent mates (first 0x40 then last 0x80, same name): the order samtools sort -n /
-//     collate and the reference's fastq-to-bam produce; anything else is an error, not a silent mis-pairing.
+//   * paired records (0x1): adjacent mates (the order samtools sort -n / collate and the reference's fastq-to-bam produce)
+//     are paired on the spot; in any other order (coordinate-sorted files) a record waits, keyed by read name, until its
+//     mate shows up — what the reference obtains from its samtools sort -n staging; a read whose mate never comes is
+//     handed on with an empty partner.
 // BGZF is a series of gzip members of <= 64 KiB, each carrying its compressed size in a 'BC' extra field (SAM spec §4.1),
 // so members inflate independently: a refill reads a run of whole blocks and inflates them on `threads` workers, each into
 // its own slice of the output (sizes come from the ISIZE trailers) with the decoder of nb_inflate.cpp, CRC of every block checked. A gzip file
@@ -22,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "nb_inflate.h"
@@ -29,7 +32,10 @@
 
 namespace {
 
-struct Tmpl { size_t a, b; uint32_t a_size, b_size; };   // offsets (into ubuf) and sizes of the record bodies; b = SIZE_MAX when single-end
+// offsets and sizes of the record bodies of one template; an offset of SIZE_MAX = that mate is absent (single-end input, or an
+// orphan of a paired file); side bit 0 / 1 = record a / b lives in the side arena (a mate that waited for its partner)
+// instead of the inflated window
+struct Tmpl { size_t a, b; uint32_t a_size, b_size; uint32_t side; };
 
 template <class F>
 void parallel_for(int T, F&& f) {
@@ -54,6 +60,11 @@ struct nb_bam {
   std::string error;
   int64_t record = 0;
   int paired = -1;             // -1 unknown, 0 single-end, 1 adjacent mates (fixed by the first primary record)
+  // a paired file that is not collated by name (e.g. coordinate-sorted): a record whose mate is not the next primary
+  // record waits here, keyed by read name, until the mate shows up (the reference gets the same effect from its
+  // samtools sort -n staging, nimble/__main__.py:344-347); what is still waiting at the end of the file is an orphan
+  std::unordered_map<std::string, std::vector<uint8_t>> waiting;
+  std::vector<uint8_t> side;   // records of pending templates that came out of `waiting`
   // templates gathered but not yet packed (a batch may end before them: see nb_bam_next_batch_tight)
   std::vector<Tmpl> pend;
   size_t pend_next_upos = 0;
@@ -167,16 +178,26 @@ void pack_seq(const Fields& f, int nwb, int64_t stride, uint64_t* w) {
   for (int64_t z = nwb + ((word + 1) >> 1); z < stride; ++z) w[z] = 0;
 }
 
-// gathers up to max_t templates starting at upos into b->pend (offsets only; nothing is consumed until they are packed)
+// gathers up to max_t templates starting at upos into b->pend (offsets only; the window is not consumed until they are packed)
 int32_t gather(nb_bam* b, int64_t max_t) {
-  b->pend.clear(); b->pend_l1 = b->pend_l2 = 0; b->have_pend = false;
+  b->pend.clear(); b->side.clear(); b->pend_l1 = b->pend_l2 = 0; b->have_pend = false;
   size_t cursor = b->upos;
   int& paired = b->paired;
+  auto to_side = [&](const std::vector<uint8_t>& rec) { const size_t o = b->side.size(); b->side.insert(b->side.end(), rec.begin(), rec.end()); return o; };
   while ((int64_t)b->pend.size() < max_t) {
     size_t off; uint32_t size;
     const int r = next_record(b, &cursor, &off, &size);
-    if (r == 0) break;
     if (r < 0) return r;
+    if (r == 0) {                                       // end of file: what still waits for a mate is an orphan
+      if (b->waiting.empty()) break;
+      auto it = b->waiting.begin();
+      Fields o; parse(it->second.data(), it->second.size(), o);
+      const size_t so = to_side(it->second); const uint32_t sz = (uint32_t)it->second.size();
+      if (o.flag & 0x80) { b->pend.push_back(Tmpl{SIZE_MAX, so, 0, sz, 2u}); b->pend_l2 = std::max(b->pend_l2, o.l_seq); }
+      else { b->pend.push_back(Tmpl{so, SIZE_MAX, sz, 0, 1u}); b->pend_l1 = std::max(b->pend_l1, o.l_seq); }
+      b->waiting.erase(it);
+      continue;
+    }
     Fields f;
     if (!parse(b->ubuf.data() + off, size, f)) { nb::set_error("BAM: malformed record " + std::to_string(b->record)); return NB_ERR_INVALID; }
     ++b->record;
@@ -185,12 +206,13 @@ int32_t gather(nb_bam* b, int64_t max_t) {
     if (paired < 0) paired = is_paired ? 1 : 0;
     if ((paired == 1) != is_paired) { nb::set_error("BAM: mixed single-end and paired records"); return NB_ERR_UNSUPPORTED; }
     if (!is_paired) {
-      b->pend.push_back(Tmpl{off, SIZE_MAX, size, 0});
+      b->pend.push_back(Tmpl{off, SIZE_MAX, size, 0, 0u});
       b->pend_l1 = std::max(b->pend_l1, f.l_seq);
       continue;
     }
-    // the mate must be the next primary record
+    // fast path: the mate is the next primary record (name-collated files, the reference's fastq-to-bam output)
     Fields g; bool got = false; size_t off2 = 0; uint32_t size2 = 0;
+    const size_t cursor_after_f = cursor; const int64_t record_after_f = b->record;
     for (;;) {
       const int r2 = next_record(b, &cursor, &off2, &size2);
       if (r2 < 0) return r2;
@@ -200,29 +222,44 @@ int32_t gather(nb_bam* b, int64_t max_t) {
       if (g.flag & 0x900) continue;
       got = true; break;
     }
-    if (got) parse(b->ubuf.data() + off, size, f);      // (the buffer may have moved while the mate was read)
-    const bool names_match = got && f.l_name == g.l_name && std::memcmp(f.name, g.name, (size_t)f.l_name) == 0;
-    if (!got || !names_match || !(g.flag & 0x1) || ((f.flag & 0xC0) == (g.flag & 0xC0))) {
-      nb::set_error("BAM: paired records are not adjacent mates near record " + std::to_string(b->record) +
-                    " (collate the file by read name: the reference itself runs samtools sort -n, nimble/__main__.py:344-347)");
-      return NB_ERR_UNSUPPORTED;
+    parse(b->ubuf.data() + off, size, f);               // (the buffer may have moved while the next record was read)
+    const bool mates = got && (g.flag & 0x1) && f.l_name == g.l_name && std::memcmp(f.name, g.name, (size_t)f.l_name) == 0 && ((f.flag & 0xC0) != (g.flag & 0xC0));
+    if (mates) {
+      const bool f_first = (f.flag & 0x40) || !(g.flag & 0x40);
+      if (f_first) { b->pend.push_back(Tmpl{off, off2, size, size2, 0u}); b->pend_l1 = std::max(b->pend_l1, f.l_seq); b->pend_l2 = std::max(b->pend_l2, g.l_seq); }
+      else { b->pend.push_back(Tmpl{off2, off, size2, size, 0u}); b->pend_l1 = std::max(b->pend_l1, g.l_seq); b->pend_l2 = std::max(b->pend_l2, f.l_seq); }
+      continue;
     }
-    const bool f_first = (f.flag & 0x40) || !(g.flag & 0x40);
-    if (f_first) { b->pend.push_back(Tmpl{off, off2, size, size2}); b->pend_l1 = std::max(b->pend_l1, f.l_seq); b->pend_l2 = std::max(b->pend_l2, g.l_seq); }
-    else { b->pend.push_back(Tmpl{off2, off, size2, size}); b->pend_l1 = std::max(b->pend_l1, g.l_seq); b->pend_l2 = std::max(b->pend_l2, f.l_seq); }
+    // not collated by name: f pairs with a record seen earlier, or waits; the record after it is looked at again
+    cursor = cursor_after_f; b->record = record_after_f;
+    std::string key((const char*)f.name, (size_t)f.l_name);
+    auto it = b->waiting.find(key);
+    if (it == b->waiting.end()) {
+      if (b->waiting.size() >= ((size_t)1 << 26)) { nb::set_error("BAM: more than 2^26 reads wait for their mates (collate the file by read name)"); return NB_ERR_UNSUPPORTED; }
+      b->waiting.emplace(std::move(key), std::vector<uint8_t>(b->ubuf.data() + off, b->ubuf.data() + off + size));
+      continue;
+    }
+    Fields o; parse(it->second.data(), it->second.size(), o);
+    if ((o.flag & 0xC0) == (f.flag & 0xC0)) { nb::set_error("BAM: two records of read '" + key.substr(0, key.find('\0')) + "' claim the same end of the pair"); return NB_ERR_INVALID; }
+    const size_t so = to_side(it->second); const uint32_t sz = (uint32_t)it->second.size();
+    const bool f_first = (f.flag & 0x40) || !(o.flag & 0x40);
+    if (f_first) { b->pend.push_back(Tmpl{off, so, size, sz, 2u}); b->pend_l1 = std::max(b->pend_l1, f.l_seq); b->pend_l2 = std::max(b->pend_l2, o.l_seq); }
+    else { b->pend.push_back(Tmpl{so, off, sz, size, 1u}); b->pend_l1 = std::max(b->pend_l1, o.l_seq); b->pend_l2 = std::max(b->pend_l2, f.l_seq); }
+    b->waiting.erase(it);
   }
   b->pend_next_upos = cursor;
   b->have_pend = true;
   return NB_OK;
 }
 
-// packs the gathered templates at layouts (len1, len2) and consumes them
-void pack_pending(nb_bam* b, int32_t len1, int32_t len2, uint64_t* r1_words, uint16_t* r1_lens, uint64_t* r2_words, uint16_t* r2_lens,
+// packs the first `count` gathered templates at layouts (len1, len2); the window is consumed once all of them are packed
+// (a gather is never redone: it moves records in and out of `waiting`)
+void pack_pending(nb_bam* b, int64_t count, int32_t len1, int32_t len2, uint64_t* r1_words, uint16_t* r1_lens, uint64_t* r2_words, uint16_t* r2_lens,
                   char* cb_out, char* ub_out, int32_t tag_width) {
-  const int64_t n = (int64_t)b->pend.size();
+  const int64_t n = std::min<int64_t>(count, (int64_t)b->pend.size());
   const int nwb1 = (len1 + 31) / 32, nwb2 = (len2 + 31) / 32;
   const int64_t s1 = nb_packed_stride_words(len1), s2 = b->paired == 1 ? nb_packed_stride_words(len2) : 0;
-  const uint8_t* base = b->ubuf.data();
+  const uint8_t* base = b->ubuf.data(); const uint8_t* side = b->side.data();
   const int T = (int)std::min<int64_t>(b->threads, std::max<int64_t>(1, n / 2048));
   auto put_tag = [&](const Fields& f, const char* t, char* dst) {
     std::memset(dst, 0, (size_t)tag_width);
@@ -232,14 +269,19 @@ void pack_pending(nb_bam* b, int32_t len1, int32_t len2, uint64_t* r1_words, uin
   parallel_for(T, [&](int t) {
     for (int64_t i = n * t / T, e = n * (t + 1) / T; i < e; ++i) {
       const Tmpl& m = b->pend[(size_t)i];
-      Fields f; parse(base + m.a, m.a_size, f);
-      pack_seq(f, nwb1, s1, r1_words + i * s1); r1_lens[i] = (uint16_t)f.l_seq;
-      put_tag(f, "CB", cb_out + i * tag_width); put_tag(f, "UB", ub_out + i * tag_width);   // the r1 version of the tags (__main__.py:236-237)
-      if (m.b != SIZE_MAX) { Fields g; parse(base + m.b, m.b_size, g); pack_seq(g, nwb2, s2, r2_words + i * s2); r2_lens[i] = (uint16_t)g.l_seq; }
+      Fields f, g; const bool has_a = m.a != SIZE_MAX, has_b = m.b != SIZE_MAX;
+      if (has_a) { parse(((m.side & 1u) ? side : base) + m.a, m.a_size, f); pack_seq(f, nwb1, s1, r1_words + i * s1); r1_lens[i] = (uint16_t)f.l_seq; }
+      else { std::memset(r1_words + i * s1, 0, (size_t)s1 * 8); r1_lens[i] = 0; }
+      if (b->paired == 1) {
+        if (has_b) { parse(((m.side & 2u) ? side : base) + m.b, m.b_size, g); pack_seq(g, nwb2, s2, r2_words + i * s2); r2_lens[i] = (uint16_t)g.l_seq; }
+        else { std::memset(r2_words + i * s2, 0, (size_t)s2 * 8); r2_lens[i] = 0; }
+      }
+      const Fields& tagsrc = has_a ? f : g;              // the r1 version of the tags (__main__.py:236-237); an orphan r2 speaks for itself
+      put_tag(tagsrc, "CB", cb_out + i * tag_width); put_tag(tagsrc, "UB", ub_out + i * tag_width);
     }
   });
-  b->upos = b->pend_next_upos;
-  b->pend.clear(); b->have_pend = false;
+  b->pend.erase(b->pend.begin(), b->pend.begin() + (std::ptrdiff_t)n);
+  if (b->pend.empty()) { b->upos = b->pend_next_upos; b->side.clear(); b->have_pend = false; }
 }
 
 void compact(nb_bam* b) {
@@ -298,15 +340,18 @@ int32_t nb_bam_set_threads(nb_bam* b, int32_t threads) {
 // cb_out / ub_out: tag_width bytes per template, NUL padded (missing tag = empty). *n_out = templates read (0 = end).
 int32_t nb_bam_next_batch(nb_bam* b, int64_t max_templates, int32_t max_len, uint64_t* r1_words, uint16_t* r1_lens, uint64_t* r2_words,
                           uint16_t* r2_lens, char* cb_out, char* ub_out, int32_t tag_width, int64_t* n_out, int32_t* paired_out) {
-  if (!b || !r1_words || !r1_lens || !cb_out || !ub_out || !n_out || !paired_out || tag_width < 1 || max_len < 1) { nb::set_error("nb_bam_next_batch: bad arguments"); return NB_ERR_INVALID; }
-  b->have_pend = false;        // (nothing is consumed until packed: a pending gather is simply redone)
-  compact(b);
-  const int32_t rc = gather(b, max_templates);
-  if (rc != NB_OK) return rc;
-  if (std::max(b->pend_l1, b->pend_l2) > max_len) { b->have_pend = false; nb::set_error("BAM: read of " + std::to_string(std::max(b->pend_l1, b->pend_l2)) + " bases: longer than max_len " + std::to_string(max_len)); return NB_ERR_UNSUPPORTED; }
-  if (b->paired == 1 && !b->pend.empty() && (!r2_words || !r2_lens)) { b->have_pend = false; nb::set_error("nb_bam_next_batch: paired BAM but no mate buffers"); return NB_ERR_INVALID; }
-  *n_out = (int64_t)b->pend.size(); *paired_out = b->paired == 1 ? 1 : 0;
-  pack_pending(b, max_len, max_len, r1_words, r1_lens, r2_words, r2_lens, cb_out, ub_out, tag_width);
+  if (!b || !r1_words || !r1_lens || !cb_out || !ub_out || !n_out || !paired_out || tag_width < 1 || max_len < 1 || max_templates < 0) { nb::set_error("nb_bam_next_batch: bad arguments"); return NB_ERR_INVALID; }
+  if (!b->have_pend) {
+    compact(b);
+    const int32_t rc = gather(b, max_templates);
+    if (rc != NB_OK) return rc;
+  }
+  if (std::max(b->pend_l1, b->pend_l2) > max_len) { nb::set_error("BAM: read of " + std::to_string(std::max(b->pend_l1, b->pend_l2)) + " bases: longer than max_len " + std::to_string(max_len)); return NB_ERR_UNSUPPORTED; }
+  if (b->paired == 1 && !b->pend.empty() && (!r2_words || !r2_lens)) { nb::set_error("nb_bam_next_batch: paired BAM but no mate buffers"); return NB_ERR_INVALID; }
+  const int64_t m = std::min<int64_t>(max_templates, (int64_t)b->pend.size());
+  *n_out = m; *paired_out = b->paired == 1 ? 1 : 0;
+  if (b->pend.empty()) b->have_pend = false;
+  else pack_pending(b, m, max_len, max_len, r1_words, r1_lens, r2_words, r2_lens, cb_out, ub_out, tag_width);
   return NB_OK;
 }
 
@@ -320,10 +365,6 @@ int32_t nb_bam_next_batch_tight(nb_bam* b, int64_t max_templates, int32_t cap_le
   constexpr int64_t SUB = 32768;
   int64_t n = 0; int32_t len1 = 1, len2 = 1;
   while (n < max_templates) {
-    if (b->have_pend && (int64_t)b->pend.size() > max_templates - n) {
-      if (n > 0) break;
-      b->have_pend = false;
-    }
     if (!b->have_pend) {
       compact(b);
       const int32_t rc = gather(b, std::min<int64_t>(SUB, max_templates - n));
@@ -334,9 +375,9 @@ int32_t nb_bam_next_batch_tight(nb_bam* b, int64_t max_templates, int32_t cap_le
     if (b->paired == 1 && (!r2_words || !r2_lens)) { nb::set_error("nb_bam_next_batch_tight: paired BAM but no mate buffers"); return NB_ERR_INVALID; }
     if (n == 0) { len1 = std::max(b->pend_l1, 1); len2 = std::max(b->pend_l2, 1); }
     else if (b->pend_l1 > len1 || b->pend_l2 > len2) break;
-    const int64_t m = (int64_t)b->pend.size();
+    const int64_t m = std::min<int64_t>((int64_t)b->pend.size(), max_templates - n);   // (what does not fit stays gathered)
     const int64_t s1 = nb_packed_stride_words(len1), s2 = nb_packed_stride_words(len2);
-    pack_pending(b, len1, len2, r1_words + n * s1, r1_lens + n, r2_words ? r2_words + n * s2 : nullptr, r2_lens ? r2_lens + n : nullptr,
+    pack_pending(b, m, len1, len2, r1_words + n * s1, r1_lens + n, r2_words ? r2_words + n * s2 : nullptr, r2_lens ? r2_lens + n : nullptr,
                  cb_out + n * tag_width, ub_out + n * tag_width, tag_width);
     n += m;
   }

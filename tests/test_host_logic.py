@@ -303,11 +303,43 @@ def test_bam_reader_single_and_paired(built, tmp_path):
     assert (b["words"] == engine.pack_reads([s1, s2], 60)[0]).all() and (b["mate_words"] == engine.pack_reads([s2, s3], 40)[0]).all()
     assert b["cb"][1].tobytes().rstrip(b"\x00") == b"GGGG"
     r.close()
-    p3 = tmp_path / "bad.bam"
-    write_bam(p3, [pairs[0], pairs[3]])                                                          # mates not adjacent
-    r = BamReader(str(p3))
+    # mates that are not adjacent (a coordinate-sorted file): paired through the waiting map; orphans come out at the end with
+    # an empty partner; two records claiming the same end of a pair are an error
+    rng2 = np.random.default_rng(12)
+    tmpl = [("t%03d" % i, "".join("ACGT"[c] for c in rng2.integers(0, 4, int(rng2.integers(20, 60)))),
+             "".join("ACGT"[c] for c in rng2.integers(0, 4, int(rng2.integers(20, 60))))) for i in range(300)]
+    recs2 = []
+    for name, a, c in tmpl:
+        recs2.append({"name": name, "flag": 77, "seq": a, "tags": {"CB": "CB" + name, "UB": "UA"}})
+        recs2.append({"name": name, "flag": 141, "seq": c, "tags": {"CB": "CB" + name, "UB": "UA"}})
+    order = rng2.permutation(len(recs2))
+    shuffled = [recs2[i] for i in order] + [{"name": "orphan1", "flag": 77, "seq": "ACGTACGTAC", "tags": {"CB": "O1"}},
+                                              {"name": "orphan2", "flag": 141, "seq": "TTTTGGGGCC", "tags": {"CB": "O2"}}]
+    shuffled.insert(5, {"name": "supp", "flag": 0x801, "seq": "ACGT"})
+    p3 = tmp_path / "shuffled.bam"
+    write_bam(p3, shuffled, block=500)
+    for batch in (1000, 37):
+        r = BamReader(str(p3), 2)
+        got = {}
+        while True:
+            b = r.next_batch(batch, 100)
+            if b["n"] == 0:
+                break
+            assert b["paired"]
+            for i in range(b["n"]):
+                cb = b["cb"][i].tobytes().rstrip(b"\x00").decode()
+                got[cb] = (engine.unpack_read(b["words"][i], int(b["lens"][i]), b["max_len"]),
+                           engine.unpack_read(b["mate_words"][i], int(b["mate_lens"][i]), b["mate_max_len"]))
+        r.close()
+        want = {"CB" + name: (a, c) for name, a, c in tmpl}
+        want["O1"] = ("ACGTACGTAC", ""); want["O2"] = ("", "TTTTGGGGCC")
+        assert got == want
+    p4 = tmp_path / "dup.bam"
+    write_bam(p4, [pairs[0], pairs[3], dict(pairs[0])])
+    r = BamReader(str(p4))
     with pytest.raises(engine._lib.NimbleError):
-        r.next_batch(10, 100)
+        while r.next_batch(10, 100)["n"]:
+            pass
     r.close()
     # a larger file: several refills, worker threads, sub-batches, a plain-gzip (non-BGZF) copy, a corrupted block
     rng = np.random.default_rng(5)
