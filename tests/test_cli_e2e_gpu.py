@@ -239,3 +239,42 @@ def test_bam_input_single_end_and_pairs(built, tmp_path):
             feats = lib.feature_list(engine.bits_to_members(ora["set_bits"][i]))
             want2.append("\t".join([",".join(feats), str(ora["mates"][i]), f"CELL{i % 7}", f"UMI{i % 90:03d}"] + [str(x) for x in ora["cov"][i]]))
     assert open(out2).read().split("\n")[1:-1] == want2 and len(want2) > 300
+
+
+def test_bam_pairs_in_any_record_order_and_orphans(built, tmp_path):
+    """A paired BAM that is NOT collated by name (mates far apart, as after a coordinate sort) plus reads whose mate is missing:
+    the reader pairs by read name and hands orphans on with an empty partner; calls equal the oracle's on the same templates."""
+    from oracle import oracle
+    from tests.helpers import write_bam
+    lib_path, names, seqs, strs, lineage = make_library(tmp_path, intersect_level=1)
+    lib = library.Library(str(lib_path))
+    rng = np.random.default_rng(31)
+    n = 600
+    r1 = [synth.codes_to_str(c) for c in synth.synth_reads(seqs, n, 90, seed=41)]
+    r2 = [synth.codes_to_str(c) for c in synth.synth_reads(seqs, n, 75, seed=42)]
+    recs = []
+    for i in range(n):
+        t = {"CB": f"CELL{i:04d}", "UB": f"UMI{i % 90:03d}"}
+        if i % 40 != 7:
+            recs.append({"name": f"p{i}", "flag": 77, "seq": r1[i], "tags": t})
+        else:
+            r1[i] = ""                                                  # orphan: only the second mate is in the file
+        if i % 40 != 13:
+            recs.append({"name": f"p{i}", "flag": 141, "seq": r2[i], "tags": t})
+        else:
+            r2[i] = ""
+    recs = [recs[j] for j in rng.permutation(len(recs))]
+    write_bam(tmp_path / "shuffled.bam", recs)
+    out = tmp_path / "shuffled.tsv"
+    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(tmp_path / "shuffled.bam")]) == 0
+    c = lib.config
+    cfg = engine.make_config(k=lib.k, score_threshold=c["score_threshold"], score_filter=c["score_filter"], score_percent=c["score_percent"],
+                             intersect_level=c["intersect_level"])
+    ora = oracle.OracleIndex(lib.sequences, lib.k).align_strs(cfg, r1, r2, n_threads=4)
+    want = set()
+    for i in range(n):
+        if ora["reason"][i] == 0:
+            feats = lib.feature_list(engine.bits_to_members(ora["set_bits"][i]))
+            want.add("\t".join([",".join(feats), str(ora["mates"][i]), f"CELL{i:04d}", f"UMI{i % 90:03d}"] + [str(x) for x in ora["cov"][i]]))
+    got = open(out).read().split("\n")[1:-1]
+    assert len(got) == len(set(got)) and set(got) == want and len(want) > 300     # (row order follows the pairing order, not the file's)
