@@ -194,6 +194,14 @@ int32_t nb_class_features(int64_t n_rows, int32_t words, const uint64_t* rows, i
                           const char* const* feature_names, int32_t n_features, int32_t max_hits, int32_t multi_hits, char* blob,
                           int64_t blob_cap, int64_t* offsets, char* sorted_blob, int64_t sorted_cap, int64_t* sorted_offsets, int32_t* reasons);
 
+/* ---- `nimble fastq-to-bam` (host): 10x R1/R2 FASTQ(.gz) -> unaligned BAM with the whitelist-corrected cell barcode (CB:Z)
+ * and the raw UMI (UB:Z) on both mates; restates fastq_to_bam_with_barcodes / process_pair,
+ * /root/reference/nimble/fastq_barcode_processor.py:145-320 (filters in the same order, flags 77 / 141, header text, tag
+ * order), records in file order. stats[8] = total_pairs, written_pairs, cb_perfect_match, cb_corrected, cb_no_correction,
+ * name_mismatch, too_short, no_remaining_seq (what the reference prints, :290-317). ---- */
+int32_t nb_fastq_to_bam(const char* r1_path, const char* r2_path, nb_whitelist* wl, const char* out_bam, int32_t threads, int32_t cb_len,
+                        int32_t umi_len, int64_t* stats);
+
 /* ---- per-read TSV rows of one batch (host): replaces the Rust binary's TSV writer for barcoded input; columns
  * nimble_features, nimble_score, r1_CB, r1_UB (consumed at /root/reference/nimble/__main__.py:237-245) + the four
  * coverage scores (report_generation.py:275). class_feature[c] = feature string of class c or NULL if rejected. ---- */

@@ -1,8 +1,8 @@
-"""Command line: `python -m nimble_amd {generate,align,report}` with the reference's flags.
+"""Command line: `python -m nimble_amd {generate,align,report,fastq-to-bam}` with the reference's flags.
 
-Flag surface copied from /root/reference/nimble/__main__.py:389-418 (generate :389-392, align :394-401, report
-:403-418). `download`, `plot` and `fastq-to-bam` exist in the reference but are outside the hot path (network fetch of
-the Rust binary, HTML plotting, pysam BAM writing): they are accepted and answered with an explanatory error."""
+Flag surface copied from /root/reference/nimble/__main__.py:389-431 (generate :389-392, align :394-401, report
+:403-418, fastq-to-bam :424-431). `download` and `plot` exist in the reference but are outside the hot path (network
+fetch of the Rust binary, HTML plotting): they are accepted and answered with an explanatory error."""
 import argparse
 import sys
 
@@ -46,7 +46,16 @@ def build_parser():
     r.add_argument("-t", "--threshold", help="Proportional count threshold for filtering features (default: 0.05).", type=float, default=0.05)
     r.add_argument("--disable_thresholding", help="Disable the per-UMI proportional count thresholding algorithm.", action="store_true", default=False)
 
-    for name in ("download", "plot", "fastq-to-bam"):
+    f = sub.add_parser("fastq-to-bam")
+    f.add_argument("--r1-fastq", help="Path to R1 FASTQ file.", type=str, required=True)
+    f.add_argument("--r2-fastq", help="Path to R2 FASTQ file.", type=str, required=True)
+    f.add_argument("--map", required=True, help="Cell barcode whitelist file (one CB per line, .gz or plain text)")
+    f.add_argument("--output", help="Path for output BAM file.", type=str, required=True)
+    f.add_argument("-c", "--num_cores", help="The number of cores to use for processing.", type=int, default=1)
+    f.add_argument("--cb-length", help="Length of cell barcode (default: 16).", type=int, default=16)
+    f.add_argument("--umi-length", help="Length of UMI (default: 12).", type=int, default=12)
+
+    for name in ("download", "plot"):
         sub.add_parser(name, add_help=False)
     return parser
 
@@ -54,9 +63,9 @@ def build_parser():
 def main(argv=None):
     parser = build_parser()
     args, extra = parser.parse_known_args(argv)
-    if args.subcommand in ("download", "plot", "fastq-to-bam"):
+    if args.subcommand in ("download", "plot"):
         print(f"Error -- `{args.subcommand}` is not part of this build: the aligner is the in-tree libnimble_amd.so (nothing to "
-              "download), plots are out of scope, and 10x FASTQ is consumed directly by `align --tenx`.", file=sys.stderr)
+              "download) and plots are out of scope.", file=sys.stderr)
         return 2
     if extra:
         parser.error("unrecognized arguments: " + " ".join(extra))
@@ -68,6 +77,10 @@ def main(argv=None):
         return align(args.reference, args.output, args.input, args.num_cores, args.strand_filter, args.trim, args.tmpdir,
                      tenx=tenx, device_id=args.device, report_output=args.report_output, report_threshold=args.report_threshold,
                      report_disable_thresholding=args.report_disable_thresholding)
+    if args.subcommand == "fastq-to-bam":
+        from .fastq_to_bam import fastq_to_bam_with_barcodes
+        fastq_to_bam_with_barcodes(args.r1_fastq, args.r2_fastq, args.map, args.output, args.num_cores, args.cb_length, args.umi_length)
+        return 0
     if args.subcommand == "report":
         cols = args.summarize.split(",") if args.summarize else None
         report(args.input, args.output, cols, args.threshold, args.disable_thresholding)

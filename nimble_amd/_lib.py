@@ -84,6 +84,7 @@ SIGNATURES = {
                                        ct.c_int32, ct.c_void_p, ct.c_int64, ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_void_p, ct.c_void_p]),
     "nb_gzip_members": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.c_int32, ct.c_int32, ct.c_void_p, ct.c_int64, c_i64p]),
     "nb_gunzip_file": (ct.c_int32, [ct.c_char_p, ct.c_void_p, ct.c_int64, c_i64p]),
+    "nb_fastq_to_bam": (ct.c_int32, [ct.c_char_p, ct.c_char_p, ct.c_void_p, ct.c_char_p, ct.c_int32, ct.c_int32, ct.c_int32, c_i64p]),
     "nb_whitelist_size": (ct.c_int64, [ct.c_void_p]),
     "nb_whitelist_correct": (ct.c_int32, [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_int32, ct.c_void_p, ct.c_void_p, c_i64p]),
     "nb_format_tenx_rows": (ct.c_int32, [ct.c_int64, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.POINTER(ct.c_char_p), ct.c_int64, ct.c_void_p,

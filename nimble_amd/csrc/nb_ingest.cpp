@@ -16,6 +16,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -97,6 +98,7 @@ struct nb_fastq {
   // index of the current batch: offsets into buf
   std::vector<size_t> nl;
   std::vector<size_t> seq_b, seq_e, qual_b, qual_e;
+  std::vector<size_t> name_b, name_e;                 // the read id: header line behind '@' up to the first blank
   int64_t n_indexed = 0;
   int32_t longest = 0;
   bool indexed = false;
@@ -184,7 +186,7 @@ int next_line(nb_fastq* q, size_t* cursor, size_t* b, size_t* e) {
 
 // serial indexer: tolerates blank lines between records and words the parse errors
 int32_t index_serial(nb_fastq* q, int64_t max_reads) {
-  q->seq_b.clear(); q->seq_e.clear(); q->qual_b.clear(); q->qual_e.clear();
+  q->seq_b.clear(); q->seq_e.clear(); q->qual_b.clear(); q->qual_e.clear(); q->name_b.clear(); q->name_e.clear();
   size_t cur = 0; int64_t n = 0;
   while (n < max_reads) {
     size_t b, e;
@@ -196,6 +198,7 @@ int32_t index_serial(nb_fastq* q, int64_t max_reads) {
     if (!next_line(q, &cur, &pb, &pe) || pb == pe || q->buf[pb] != '+') { nb::set_error("FASTQ parse error: missing '+' line in record " + std::to_string(q->record + n)); return NB_ERR_INVALID; }
     if (!next_line(q, &cur, &qb, &qe)) { nb::set_error("FASTQ parse error: missing quality line"); return NB_ERR_INVALID; }
     q->seq_b.push_back(sb); q->seq_e.push_back(se); q->qual_b.push_back(qb); q->qual_e.push_back(qe);
+    { size_t ne = b + 1; while (ne < e && q->buf[ne] != ' ' && q->buf[ne] != '\t') ++ne; q->name_b.push_back(b + 1); q->name_e.push_back(ne); }
     ++n;
   }
   q->next_pos = cur; q->n_indexed = n;
@@ -244,6 +247,7 @@ int index_fast(nb_fastq* q, int64_t max_reads) {
   const int64_t n = (int64_t)std::min<size_t>((size_t)max_reads, q->nl.size() / 4);
   if (n == 0) return q->end == 0 ? 1 : 0;   // nothing left at all, or a tail the serial walker must judge
   q->seq_b.resize((size_t)n); q->seq_e.resize((size_t)n); q->qual_b.resize((size_t)n); q->qual_e.resize((size_t)n);
+  q->name_b.resize((size_t)n); q->name_e.resize((size_t)n);
   const int T = (int)std::min<int64_t>(q->threads, std::max<int64_t>(1, n / 4096));
   std::vector<int> bad((size_t)T, 0);
   const char* base = q->buf; const size_t* nl = q->nl.data();
@@ -257,6 +261,7 @@ int index_fast(nb_fastq* q, int64_t max_reads) {
       if (se > sb && base[se - 1] == '\r') --se;
       if (qe > qb && base[qe - 1] == '\r') --qe;
       q->seq_b[(size_t)i] = sb; q->seq_e[(size_t)i] = se; q->qual_b[(size_t)i] = qb; q->qual_e[(size_t)i] = qe;
+      { size_t he = nl[4 * i]; if (he > h && base[he - 1] == '\r') --he; size_t ne = h + 1; while (ne < he && base[ne] != ' ' && base[ne] != '\t') ++ne; q->name_b[(size_t)i] = h + 1; q->name_e[(size_t)i] = ne; }
     }
   });
   for (int b : bad) if (b) return 0;
@@ -430,6 +435,127 @@ int32_t nb_fastq_next_batch_tight(nb_fastq* q, int64_t max_reads, int32_t cap_le
   }
   *n_out = n; *max_len_out = batch_len;
   return NB_OK;
+}
+
+// `nimble fastq-to-bam` (/root/reference/nimble/fastq_barcode_processor.py:131-320): 10x R1/R2 FASTQ(.gz) -> unaligned BAM whose
+// records carry the whitelist-corrected cell barcode (CB:Z) and the raw UMI (UB:Z). Per pair, in file order (process_pair,
+// :145-210): ids (first word of the header, without a trailing /1 resp. /2) must agree; R1 = CB + UMI + a non-empty rest; the
+// CB is corrected against the whitelist (nb_whitelist_correct) or the pair is dropped; r1 = the rest of R1 with flag 77, r2 =
+// all of R2 with flag 141, both unplaced (refID / pos -1, bin 4680), qualities = phred, tags CB then UB. Header as the
+// reference writes it (:237-240). stats: total_pairs, written_pairs, cb_perfect_match, cb_corrected, cb_no_correction,
+// name_mismatch, too_short, no_remaining_seq (the counters the reference prints, :290-317).
+int32_t nb_fastq_to_bam(const char* r1_path, const char* r2_path, nb_whitelist* wl, const char* out_bam, int32_t threads, int32_t cb_len,
+                        int32_t umi_len, int64_t* stats) {
+  if (!r1_path || !r2_path || !wl || !out_bam || !stats || cb_len < 1 || umi_len < 0) { nb::set_error("nb_fastq_to_bam: bad arguments"); return NB_ERR_INVALID; }
+  for (int i = 0; i < 8; ++i) stats[i] = 0;
+  nb_fastq *q1 = nullptr, *q2 = nullptr;
+  int32_t rc = nb_fastq_open(r1_path, &q1); if (rc != NB_OK) return rc;
+  rc = nb_fastq_open(r2_path, &q2); if (rc != NB_OK) { nb_fastq_close(q1); return rc; }
+  nb_fastq_set_threads(q1, threads); nb_fastq_set_threads(q2, threads);
+  FILE* out = std::fopen(out_bam, "wb");
+  if (!out) { nb_fastq_close(q1); nb_fastq_close(q2); nb::set_error(std::string("nb_fastq_to_bam: cannot write ") + out_bam); return NB_ERR_INVALID; }
+  std::vector<char> raw, comp;
+  auto put32 = [](std::vector<char>& v, int32_t x) { for (int j = 0; j < 4; ++j) v.push_back((char)((uint32_t)x >> (8 * j))); };
+  {
+    const std::string text = "@HD\tVN:1.6\tSO:queryname\n@PG\tID:nimble-fastq-to-bam\tPN:nimble\tVN:1.2\tCL:whitelist-based CB correction\n";
+    raw.insert(raw.end(), {'B', 'A', 'M', 1}); put32(raw, (int32_t)text.size()); raw.insert(raw.end(), text.begin(), text.end()); put32(raw, 0);
+  }
+  auto flush = [&](bool all) -> int32_t {
+    if (raw.empty() || (!all && raw.size() < ((size_t)32 << 20))) return NB_OK;
+    const int64_t n = (int64_t)raw.size(), cap = n + (n >> 9) + 64 * ((n >> 20) + 1) + 64;
+    comp.resize((size_t)cap); int64_t got = 0;
+    const int32_t r = nb_gzip_members(raw.data(), n, 6, threads, comp.data(), cap, &got);
+    if (r != NB_OK) return r;
+    if (std::fwrite(comp.data(), 1, (size_t)got, out) != (size_t)got) { nb::set_error("nb_fastq_to_bam: write error"); return NB_ERR_INVALID; }
+    raw.clear(); return NB_OK;
+  };
+  static const uint8_t NT16[128] = {   // htslib seq_nt16_table restricted to ASCII: "=ACMGRSVTWYHKDBN", everything else N
+      15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+      15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 1, 2, 4, 8, 15, 15, 15, 15, 15, 15, 15, 15, 15, 0, 15, 15,
+      15, 1, 14, 2, 13, 15, 15, 4, 11, 15, 15, 12, 15, 3, 15, 15, 15, 15, 5, 6, 8, 15, 7, 9, 15, 10, 15, 15, 15, 15, 15, 15,
+      15, 1, 14, 2, 13, 15, 15, 4, 11, 15, 15, 12, 15, 3, 15, 15, 15, 15, 5, 6, 8, 15, 7, 9, 15, 10, 15, 15, 15, 15, 15, 15};
+  constexpr int64_t SUB = 65536;
+  std::vector<char> cb_raw, cb_qual, cb_fix; std::vector<uint8_t> cb_ok; std::vector<int64_t> cand;
+  for (;;) {
+    int64_t n1 = 0, n2 = 0;
+    rc = nb_fastq_index_batch(q1, SUB, &n1, nullptr); if (rc != NB_OK) break;
+    rc = nb_fastq_index_batch(q2, SUB, &n2, nullptr); if (rc != NB_OK) break;
+    const int64_t n = std::min(n1, n2);                 // zip(): the shorter file ends the run
+    if (n == 0) break;
+    stats[0] += n;
+    const char* b1 = q1->buf; const char* b2 = q2->buf;
+    // pass 1 (serial, cheap): the filters in the reference's order, and the barcodes that go to the corrector
+    std::vector<uint8_t> keep((size_t)n, 0);
+    cand.clear(); cb_raw.clear(); cb_qual.clear();
+    for (int64_t i = 0; i < n; ++i) {
+      size_t a0 = q1->name_b[(size_t)i], a1 = q1->name_e[(size_t)i], c0 = q2->name_b[(size_t)i], c1 = q2->name_e[(size_t)i];
+      if (a1 - a0 >= 2 && b1[a1 - 2] == '/' && b1[a1 - 1] == '1') a1 -= 2;
+      if (c1 - c0 >= 2 && b2[c1 - 2] == '/' && b2[c1 - 1] == '2') c1 -= 2;
+      if (a1 - a0 != c1 - c0 || std::memcmp(b1 + a0, b2 + c0, a1 - a0) != 0) { ++stats[5]; continue; }
+      const int64_t L1 = (int64_t)(q1->seq_e[(size_t)i] - q1->seq_b[(size_t)i]);
+      if (L1 < cb_len + umi_len) { ++stats[6]; continue; }
+      if (L1 == cb_len + umi_len) { ++stats[7]; continue; }
+      if ((int64_t)(q1->qual_e[(size_t)i] - q1->qual_b[(size_t)i]) < L1 || (q2->qual_e[(size_t)i] - q2->qual_b[(size_t)i]) < (q2->seq_e[(size_t)i] - q2->seq_b[(size_t)i])) {
+        nb::set_error("nb_fastq_to_bam: quality line shorter than the sequence in record " + std::to_string(q1->record + i)); rc = NB_ERR_INVALID; break; }
+      cand.push_back(i);
+      cb_raw.insert(cb_raw.end(), b1 + q1->seq_b[(size_t)i], b1 + q1->seq_b[(size_t)i] + cb_len);
+      cb_qual.insert(cb_qual.end(), b1 + q1->qual_b[(size_t)i], b1 + q1->qual_b[(size_t)i] + cb_len);
+    }
+    if (rc != NB_OK) break;
+    cb_fix.resize(cb_raw.size()); cb_ok.assign(cand.size(), 0);
+    int64_t wst[3] = {0, 0, 0};
+    if (!cand.empty()) { rc = nb_whitelist_correct(wl, cb_raw.data(), cb_qual.data(), (int64_t)cand.size(), cb_len, cb_fix.data(), cb_ok.data(), wst); if (rc != NB_OK) break; }
+    stats[2] = wst[0]; stats[3] = wst[1]; stats[4] = wst[2];   // (cumulative inside the corrector)
+    // pass 2 (parallel): the BAM records of the surviving pairs, in file order
+    const int64_t m = (int64_t)cand.size();
+    const int T = (int)std::min<int64_t>(threads < 1 ? 1 : threads, std::max<int64_t>(1, m / 4096));
+    std::vector<std::vector<char>> part((size_t)T);
+    std::vector<int64_t> wrote((size_t)T, 0);
+    parallel_for(T, [&](int t) {
+      std::vector<char>& v = part[(size_t)t];
+      auto p32 = [&](int32_t x) { for (int j = 0; j < 4; ++j) v.push_back((char)((uint32_t)x >> (8 * j))); };
+      auto record = [&](const char* name, size_t ln, const char* seq, const char* qual, size_t L, int flag, const char* cb, const char* umi) {
+        const size_t size = 32 + ln + 1 + (L + 1) / 2 + L + (3 + (size_t)cb_len + 1) + (3 + (size_t)umi_len + 1);
+        p32((int32_t)size); p32(-1); p32(-1);
+        v.push_back((char)(ln + 1)); v.push_back(0); v.push_back((char)(4680 & 0xff)); v.push_back((char)(4680 >> 8));   // l_read_name, mapq, bin
+        v.push_back(0); v.push_back(0); v.push_back((char)(flag & 0xff)); v.push_back((char)(flag >> 8));                 // n_cigar_op, flag
+        p32((int32_t)L); p32(-1); p32(-1); p32(0);
+        v.insert(v.end(), name, name + ln); v.push_back(0);
+        for (size_t j = 0; j < L; j += 2) { const uint8_t hi = NT16[(uint8_t)seq[j] & 127], lo = j + 1 < L ? NT16[(uint8_t)seq[j + 1] & 127] : 0; v.push_back((char)((hi << 4) | lo)); }
+        for (size_t j = 0; j < L; ++j) v.push_back((char)((uint8_t)qual[j] - 33));
+        v.push_back('C'); v.push_back('B'); v.push_back('Z'); v.insert(v.end(), cb, cb + cb_len); v.push_back(0);
+        v.push_back('U'); v.push_back('B'); v.push_back('Z'); v.insert(v.end(), umi, umi + umi_len); v.push_back(0);
+      };
+      for (int64_t k = m * t / T, e = m * (t + 1) / T; k < e; ++k) {
+        if (!cb_ok[(size_t)k]) continue;
+        const int64_t i = cand[(size_t)k];
+        size_t a0 = q1->name_b[(size_t)i], a1 = q1->name_e[(size_t)i];
+        if (a1 - a0 >= 2 && b1[a1 - 2] == '/' && b1[a1 - 1] == '1') a1 -= 2;
+        if (a1 - a0 > 254) a1 = a0 + 254;                // (BAM keeps read names below 255 bytes)
+        const char* s1 = b1 + q1->seq_b[(size_t)i]; const char* ql1 = b1 + q1->qual_b[(size_t)i];
+        const size_t L1 = q1->seq_e[(size_t)i] - q1->seq_b[(size_t)i], skip = (size_t)(cb_len + umi_len);
+        const size_t L2 = q2->seq_e[(size_t)i] - q2->seq_b[(size_t)i];
+        const char* cb = cb_fix.data() + k * cb_len; const char* umi = s1 + cb_len;
+        record(b1 + a0, a1 - a0, s1 + skip, ql1 + skip, L1 - skip, 77, cb, umi);
+        record(b1 + a0, a1 - a0, b2 + q2->seq_b[(size_t)i], b2 + q2->qual_b[(size_t)i], L2, 141, cb, umi);
+        ++wrote[(size_t)t];
+      }
+    });
+    for (int t = 0; t < T; ++t) { raw.insert(raw.end(), part[(size_t)t].begin(), part[(size_t)t].end()); stats[1] += wrote[(size_t)t]; }
+    // consume the indexed records (a batch is consumed by packing it; nothing to pack here)
+    rc = nb_fastq_pack_batch(q1, 1, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr); if (rc != NB_OK) break;
+    rc = nb_fastq_pack_batch(q2, 1, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr); if (rc != NB_OK) break;
+    rc = flush(false); if (rc != NB_OK) break;
+    if (n1 != n2) break;
+  }
+  if (rc == NB_OK) rc = flush(true);
+  if (rc == NB_OK) {
+    static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (std::fwrite(eof_block, 1, 28, out) != 28) { nb::set_error("nb_fastq_to_bam: write error"); rc = NB_ERR_INVALID; }
+  }
+  if (std::fclose(out) != 0 && rc == NB_OK) { nb::set_error("nb_fastq_to_bam: write error"); rc = NB_ERR_INVALID; }
+  nb_fastq_close(q1); nb_fastq_close(q2);
+  return rc;
 }
 
 // Reads up to max_reads records; *n_out = records read (0 = end of file).

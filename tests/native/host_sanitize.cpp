@@ -123,7 +123,18 @@ int main(int argc, char** argv) {
     const int n = 1000; std::vector<char> raw(n * 8), q(n * 8, 'I'), out(n * 8); std::vector<uint8_t> ok(n); int64_t stt[3];
     for (auto& c : raw) c = "ACGTN"[rng() % 5];
     if (nb_whitelist_correct(wl, raw.data(), q.data(), n, 8, out.data(), ok.data(), stt) != NB_OK) return 1;
+    int64_t fst[8];
+    if (nb_fastq_to_bam((dir + "/t.fastq.gz").c_str(), (dir + "/t.fastq.gz").c_str(), wl, (dir + "/conv.bam").c_str(), 3, 8, 4, fst) != NB_OK || fst[0] != 10000) { std::printf("fastq-to-bam: %s\n", nb::g.c_str()); return 1; }
     nb_whitelist_destroy(wl);
+    if (fst[1] > 0) {
+      nb_bam* cb = nullptr; int64_t total = 0, got = 0; int32_t pr = 0, l1 = 0, l2 = 0;
+      if (nb_bam_open((dir + "/conv.bam").c_str(), &cb) != NB_OK) { std::printf("conv bam: %s\n", nb::g.c_str()); return 1; }
+      nb_bam_set_threads(cb, 3);
+      std::vector<uint64_t> a((size_t)4096 * nb_packed_stride_words(160)), c2((size_t)4096 * nb_packed_stride_words(160)); std::vector<uint16_t> la(4096), lb(4096); std::vector<char> t1(4096 * 20), t2(4096 * 20);
+      do { if (nb_bam_next_batch_tight(cb, 4096, 160, a.data(), la.data(), c2.data(), lb.data(), t1.data(), t2.data(), 20, &got, &l1, &l2, &pr) != NB_OK) { std::printf("conv bam: %s\n", nb::g.c_str()); return 1; } total += got; } while (got);
+      nb_bam_close(cb);
+      if (total != fst[1] || !pr) { std::printf("conv bam: %lld templates, %lld written\n", (long long)total, (long long)fst[1]); return 1; }
+    }
     std::vector<uint32_t> cls(n), info(n); std::vector<uint64_t> cov(n);
     for (int i = 0; i < n; ++i) { cls[i] = i % 5 == 4 ? NB_NO_CLASS : i % 3; info[i] = (i % 7 ? 0u : 2u << 16) | (1u << 25) | 100; cov[i] = 100; }
     const char* feats[3] = {"A*01", nullptr, "B*02,B*03"};
