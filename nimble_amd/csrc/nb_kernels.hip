@@ -641,26 +641,41 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
       }
     }
   }
-  Tri HF, RF, LF, HR, RR, LR;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
-    const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
-    const bool hF = payF[r] != PAY_ABSENT, hR = payR[r] != PAY_ABSENT;
-    F.col[r] = payF[r] >> 10; R.col[r] = payR[r] >> 10;
-    HF.m[r] = __ballot(hF);
-    RF.m[r] = __ballot(hF && next_ok && ((payF[r] >> nextb) & 1u));
-    LF.m[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
-    HR.m[r] = __ballot(hR);
-    RR.m[r] = __ballot(hR && prev_ok && ((payR[r] >> (3u - prevb)) & 1u));
-    LR.m[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
-  }
-  Tri VF, VR;
+  // The read strand is balloted and walked before the masks of the reverse strand exist: eighteen 64-bit masks at once do not
+  // fit the scalar register file next to the kernel arguments, and every spilled SGPR costs a v_writelane / v_readlane pair.
   const int kq = K / 3, kr = K - 3 * kq, last = L - K;
-  F.cov = (HF.m[0] | HF.m[1] | HF.m[2]) ? tri_walk(HF, RF, LF, L, K, kq, kr, VF) : 0;
-  R.cov = (HR.m[0] | HR.m[1] | HR.m[2]) ? tri_walk_down(HR, RR, LR, L, K, kq, kr, TPos{last / 3, last - 3 * (last / 3)}, VR) : 0;
+  {
+    Tri HF, RF, LF, VF;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) { F.V.w[r] = F.cov ? VF.m[r] : 0ull; R.V.w[r] = R.cov ? VR.m[r] : 0ull; }
+    for (int r = 0; r < 3; ++r) {
+      const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
+      const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
+      const bool hF = payF[r] != PAY_ABSENT;
+      F.col[r] = payF[r] >> 10;
+      HF.m[r] = __ballot(hF);
+      RF.m[r] = __ballot(hF && next_ok && ((payF[r] >> nextb) & 1u));
+      LF.m[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
+    }
+    F.cov = (HF.m[0] | HF.m[1] | HF.m[2]) ? tri_walk(HF, RF, LF, L, K, kq, kr, VF) : 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) F.V.w[r] = F.cov ? VF.m[r] : 0ull;
+  }
+  {
+    Tri HR, RR, LR, VR;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
+      const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
+      const bool hR = payR[r] != PAY_ABSENT;
+      R.col[r] = payR[r] >> 10;
+      HR.m[r] = __ballot(hR);
+      RR.m[r] = __ballot(hR && prev_ok && ((payR[r] >> (3u - prevb)) & 1u));
+      LR.m[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
+    }
+    R.cov = (HR.m[0] | HR.m[1] | HR.m[2]) ? tri_walk_down(HR, RR, LR, L, K, kq, kr, TPos{last / 3, last - 3 * (last / 3)}, VR) : 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) R.V.w[r] = R.cov ? VR.m[r] : 0ull;
+  }
 }
 
 // Step 5: intern the set held in acc (lane-distributed) and return its dense class id, or NB_NO_CLASS on overflow.
@@ -738,7 +753,7 @@ __device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) 
 #define NB_SE_WAVES_PER_EU 1, 6   // measured on MI355X (10M x 150bp, 1k seqs): 6 waves/SIMD 23.4 ms, 7 -> 28.1, 8 -> 25.5:
 #endif                             // the kernel is bound by L2-miss request rate, more waves only thrash L2
 template <int NR, int TW, bool TRI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ct, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, const DevClasses* __restrict__ ctp, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   __syncthreads();
@@ -812,6 +827,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
 #if defined(NB_ABLATE) && NB_ABLATE >= 1
           cls = (uint32_t)acc[0] & 1u;   // timing-only build: no interning, no counting
 #else
+          // The class-table descriptor is fetched here, once per called read (one scalar load from the constant cache), instead
+          // of living in 16 SGPRs for the whole kernel: the masks of the walk need that room, and a spilled SGPR costs a
+          // v_writelane / v_readlane pair on the vector pipe.
+          asm volatile("" ::: "memory");
+          const DevClasses ct = *ctp;
           cls = intern_class<TW>(ct, ix.W, lane, acc);
           if (cls != NB_NO_CLASS && lane == 0) atomicAdd(&ct.counts[cls], 1ull);
 #endif
@@ -826,7 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
     }
   }
   __syncthreads();
-  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&ctp->reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1105,7 +1125,7 @@ struct nb_ctx {
   // bound index (device copies)
   nb::Bucket* d_slots = nullptr; nb::ColDesc* d_desc = nullptr; uint64_t* d_packed = nullptr; nb::KmerHash hash{}; int W = 0, K = 0, n_seqs = 0; int64_t index_bytes = 0;
   // class table
-  nb::DevClasses ct{}; int64_t max_classes = 0;
+  nb::DevClasses ct{}; nb::DevClasses* d_ct = nullptr; int64_t max_classes = 0;   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
   // score_percent table
   uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0; std::vector<uint16_t> pct_host;
 };
@@ -1145,7 +1165,7 @@ static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStrea
   if (!cached_blocks || cached_cu != c->n_cu) { cached_blocks = resident_blocks(c, nb_align_se_kernel<NR, TW, TRI>, 1ll << 40); cached_cu = c->n_cu; }
   long long blocks = cached_blocks; const long long need = (a.n + 3) / 4;
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW, TRI>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a, a.reads);
+  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW, TRI>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (const DevClasses*)c->d_ct, a, a.reads);
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
@@ -1223,7 +1243,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
 
@@ -1285,6 +1305,8 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   NB_HIP(hipMemcpy(c->d_desc, h.desc.data(), h.desc.size() * sizeof(ColDesc), hipMemcpyHostToDevice));
   NB_HIP(hipMemcpy(c->d_packed, h.packed.data(), h.packed.size() * 8, hipMemcpyHostToDevice));
   NB_HIP(hipMalloc((void**)&c->ct.rows, (size_t)c->max_classes * (size_t)h.words * 8));
+  if (!c->d_ct) NB_HIP(hipMalloc((void**)&c->d_ct, sizeof(DevClasses)));
+  NB_HIP(hipMemcpy(c->d_ct, &c->ct, sizeof(DevClasses), hipMemcpyHostToDevice));
   c->hash = h.hash; c->W = h.words; c->K = h.k; c->n_seqs = h.n_seqs;
   c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
