@@ -753,7 +753,7 @@ __device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) 
 #define NB_SE_WAVES_PER_EU 1, 6   // measured on MI355X (10M x 150bp, 1k seqs): 6 waves/SIMD 23.4 ms, 7 -> 28.1, 8 -> 25.5:
 #endif                             // the kernel is bound by L2-miss request rate, more waves only thrash L2
 template <int NR, int TW, bool TRI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, const DevClasses* __restrict__ ctp, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ctv, const DevClasses* __restrict__ ctp, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   __syncthreads();
@@ -827,11 +827,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
 #if defined(NB_ABLATE) && NB_ABLATE >= 1
           cls = (uint32_t)acc[0] & 1u;   // timing-only build: no interning, no counting
 #else
-          // The class-table descriptor is fetched here, once per called read (one scalar load from the constant cache), instead
-          // of living in 16 SGPRs for the whole kernel: the masks of the walk need that room, and a spilled SGPR costs a
-          // v_writelane / v_readlane pair on the vector pipe.
-          asm volatile("" ::: "memory");
-          const DevClasses ct = *ctp;
+          // Three-per-lane variant: the class-table descriptor is fetched here, once per called read (one scalar load from the
+          // constant cache), instead of living in 16 SGPRs for the whole kernel: the masks of the walk need that room, and a
+          // spilled SGPR costs a v_writelane / v_readlane pair on the vector pipe. The other variants have the room and keep
+          // it in registers (the per-read scalar load costs them 14 %: 134 -> 153 ms on the 91-bp workload).
+          DevClasses ct = ctv;
+          if constexpr (TRI) { asm volatile("" ::: "memory"); ct = *ctp; }
           cls = intern_class<TW>(ct, ix.W, lane, acc);
           if (cls != NB_NO_CLASS && lane == 0) atomicAdd(&ct.counts[cls], 1ull);
 #endif
@@ -1152,7 +1153,11 @@ template <class K>
 static int resident_blocks(nb_ctx* c, K kernel, long long n_templates) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-  if (per_cu > 8) per_cu = 8;
+  // one block = one wave per SIMD. Beyond 6 waves per SIMD the extra waves only evict each other's table lines from L2
+  // (measured on the 91-bp workload: 133 ms at 6, 153 ms at 7; profiles/r01_tuning_notes.md), so the grid stops there.
+  int cap = 6;
+  if (const char* e = std::getenv("NB_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) cap = v; }
+  if (per_cu > cap) per_cu = cap;
   long long blocks = (long long)c->n_cu * per_cu;
   const long long need = (n_templates + 3) / 4;
   if (blocks > need) blocks = need;
@@ -1162,10 +1167,10 @@ static int resident_blocks(nb_ctx* c, K kernel, long long n_templates) {
 template <int NR, int TW, bool TRI>
 static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
   static thread_local int cached_blocks = 0; static thread_local int cached_cu = 0;
-  if (!cached_blocks || cached_cu != c->n_cu) { cached_blocks = resident_blocks(c, nb_align_se_kernel<NR, TW, TRI>, 1ll << 40); cached_cu = c->n_cu; }
+  if (!cached_blocks || cached_cu != c->n_cu || std::getenv("NB_BLOCKS_PER_CU")) { cached_blocks = resident_blocks(c, nb_align_se_kernel<NR, TW, TRI>, 1ll << 40); cached_cu = c->n_cu; }
   long long blocks = cached_blocks; const long long need = (a.n + 3) / 4;
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW, TRI>), dim3((unsigned)blocks), dim3(256), 0, s, ix, (const DevClasses*)c->d_ct, a, a.reads);
+  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW, TRI>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, (const DevClasses*)c->d_ct, a, a.reads);
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
