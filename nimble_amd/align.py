@@ -105,6 +105,7 @@ class BamReader:
         _lib.check(_lib.lib().nb_bam_set_threads(self._h, int(threads)))
         self._pinned = pinned
         self._sets, self._turn = {}, 0
+        self._has_mates = False
 
     _buffers = FastqReader._buffers
 
@@ -114,15 +115,28 @@ class BamReader:
         self._turn += 1
         cap = engine.packed_stride_words(max_len)
         f1 = self._buffers("w1", max_reads, (cap,), np.uint64).reshape(-1); l1 = self._buffers("l1", max_reads, (), np.uint16)
-        f2 = self._buffers("w2", max_reads, (cap,), np.uint64).reshape(-1); l2 = self._buffers("l2", max_reads, (), np.uint16)
         cb = self._buffers("cb", max_reads, (self.TAG_WIDTH,), "S1"); ub = self._buffers("ub", max_reads, (self.TAG_WIDTH,), "S1")
         n, paired, len1, len2 = ct.c_int64(), ct.c_int32(), ct.c_int32(), ct.c_int32()
-        _lib.check(_lib.lib().nb_bam_next_batch_tight(self._h, max_reads, max_len, f1.ctypes.data, l1.ctypes.data, f2.ctypes.data, l2.ctypes.data,
-                                                      cb.ctypes.data, ub.ctypes.data, self.TAG_WIDTH, ct.byref(n), ct.byref(len1), ct.byref(len2),
-                                                      ct.byref(paired)))
+        while True:
+            f2 = l2 = None
+            if self._has_mates:     # mate buffers only once the file has shown pairs (most 10x BAMs are single-end)
+                f2 = self._buffers("w2", max_reads, (cap,), np.uint64).reshape(-1); l2 = self._buffers("l2", max_reads, (), np.uint16)
+            try:
+                _lib.check(_lib.lib().nb_bam_next_batch_tight(self._h, max_reads, max_len, f1.ctypes.data, l1.ctypes.data,
+                                                              f2.ctypes.data if f2 is not None else None, l2.ctypes.data if l2 is not None else None,
+                                                              cb.ctypes.data, ub.ctypes.data, self.TAG_WIDTH, ct.byref(n), ct.byref(len1), ct.byref(len2),
+                                                              ct.byref(paired)))
+                break
+            except _lib.NimbleError as e:
+                if self._has_mates or "no mate buffers" not in str(e):
+                    raise
+                self._has_mates = True   # (the gathered templates stay pending in the reader: nothing is lost)
         k, s1, s2 = n.value, engine.packed_stride_words(len1.value), engine.packed_stride_words(len2.value)
-        return {"n": k, "paired": bool(paired.value), "words": f1[:k * s1].reshape(k, s1), "lens": l1[:k], "max_len": len1.value,
-                "mate_words": f2[:k * s2].reshape(k, s2), "mate_lens": l2[:k], "mate_max_len": len2.value, "cb": cb[:k], "umi": ub[:k]}
+        out = {"n": k, "paired": bool(paired.value), "words": f1[:k * s1].reshape(k, s1), "lens": l1[:k], "max_len": len1.value,
+               "mate_words": None, "mate_lens": None, "mate_max_len": len2.value, "cb": cb[:k], "umi": ub[:k]}
+        if f2 is not None:
+            out.update(mate_words=f2[:k * s2].reshape(k, s2), mate_lens=l2[:k])
+        return out
 
     def close(self):
         if self._h:
