@@ -109,3 +109,67 @@ def test_pairs_and_intersect_levels(built, lib):
     # both mates reverse-oriented template: orientation R
     r = run(strs, [r2], [r1])
     assert r["orientation"][0] == 1 and r["score"][0] == 180
+
+
+@pytest.mark.parametrize("k", [5, 12, 20])
+def test_cpp_oracle_equals_the_pure_python_reading_of_the_spec(built, k):
+    """oracle/spec_py.py restates docs/SPEC.md §1-§4 a second time (sets and string slices, written from the text): the C++
+    oracle must agree with it on every field for random polymorphic libraries, reads with errors / Ns / short lengths, pairs,
+    every intersect level, strand filter, mismatch budget and filter setting; the index facts (extensions, unitig-interior
+    flags, colours) too."""
+    from oracle import oracle, spec_py
+    rng = np.random.default_rng(100 + k)
+    for trial in range(6):
+        anc = [_rand(rng, int(rng.integers(60, 160))) for _ in range(3)]
+        seqs = []
+        for a in anc:
+            for _ in range(int(rng.integers(2, 6))):
+                s = list(a)
+                for _ in range(int(rng.integers(0, 5))):
+                    s[int(rng.integers(0, len(s)))] = "ACGTN"[int(rng.integers(0, 5))]
+                seqs.append("".join(s))
+        seqs.append(_rand(rng, k - 1))                       # too short to hold a k-mer
+        seqs.append(seqs[0][:k + 3].lower())                 # lower case, shares k-mers with sequence 0
+        spec = spec_py.SpecIndex(seqs, k)
+        oix = oracle.OracleIndex(seqs, k)
+        # index facts
+        assert oix.num_kmers == len(spec.colour)
+        for x in list(spec.colour)[:: max(1, len(spec.colour) // 150)]:
+            q = oix.query(x)
+            assert q is not None and q["members"] == sorted(spec.colour[x])
+            assert {"ACGT"[b] for b in range(4) if q["rext"] >> b & 1} == spec.rext[x] and {"ACGT"[b] for b in range(4) if q["lext"] >> b & 1} == spec.lext[x]
+            assert bool(q["r_internal"]) == spec.r_internal(x) and bool(q["l_internal"]) == spec.l_internal(x)
+        # reads
+        reads, mates = [], []
+        for _ in range(120):
+            def draw():
+                kind = rng.random()
+                if kind < 0.12:
+                    return _rand(rng, int(rng.integers(0, 70)))
+                src = seqs[int(rng.integers(0, len(seqs) - 2))]
+                L = int(rng.integers(max(1, k - 3), min(len(src), 90) + 1))
+                st = int(rng.integers(0, len(src) - L + 1))
+                r = list(src[st:st + L])
+                for _ in range(int(rng.integers(0, 4))):
+                    if r:
+                        r[int(rng.integers(0, len(r)))] = "ACGTN"[int(rng.integers(0, 5))]
+                r = "".join(r)
+                return r if rng.random() < 0.5 else spec_py.revcomp(r)
+            reads.append(draw()); mates.append(draw())
+        for cfgkw in (dict(), dict(num_mismatches=1), dict(num_mismatches=3, intersect_level=2), dict(intersect_level=1, require_valid_pair=True),
+                      dict(discard_multiple_matches=True, score_percent=0.3), dict(strand_filter="fiveprime", score_threshold=k, score_filter=k),
+                      dict(strand_filter="threeprime", score_filter=60), dict(score_threshold=40, score_percent=0.8)):
+            kw = dict(k=k, score_threshold=min(20, k + 2), score_filter=min(25, k + 4))
+            kw.update(cfgkw)
+            cfg = engine.make_config(**kw)
+            cfgd = dict(score_threshold=cfg.score_threshold, score_filter=cfg.score_filter, score_percent=cfg.score_percent,
+                        num_mismatches=cfg.num_mismatches, discard_multiple_matches=bool(cfg.discard_multiple_matches),
+                        intersect_level=cfg.intersect_level, require_valid_pair=bool(cfg.require_valid_pair), strand_filter=cfg.strand_filter)
+            for paired in (False, True):
+                got = oix.align_strs(cfg, reads, mates if paired else None)
+                for i, r in enumerate(reads):
+                    want = spec_py.align_template(spec, cfgd, r, mates[i] if paired else None)
+                    have = dict(reason=int(got["reason"][i]), score=int(got["score"][i]), orientation=int(got["orientation"][i]), mates=int(got["mates"][i]),
+                                set=members(got["set_bits"][i]), cov=[int(x) for x in got["cov"][i]])
+                    assert have == want, (k, trial, cfgkw, paired, i, r, mates[i] if paired else None)
+        oix.close()
