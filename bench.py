@@ -177,7 +177,7 @@ def main():
 
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
     # from the committed rocprofv3 PMC passes of the SAME workload (scripts/profile_gpu.sh -> profiles/*_traffic.json).
-    traffic, traffic_src, miss_requests = None, None, None
+    traffic, traffic_src, miss_requests, sq = None, None, None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
@@ -187,6 +187,7 @@ def main():
         if (t.get("reads_per_gpu"), t.get("read_len"), t.get("n_seqs"), t.get("k")) == (n, L, len(strs), args.k) and "traffic_bytes_per_launch" in t:
             traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.basename(f)
             miss_requests = t.get("TCC_MISS_sum")
+            sq = t.get("sq_per_read")
 
     # ---- optional: per-cell counts for the 10x workload (BASELINE configs[2] asks for them), outside the timed region ----
     per_cell = None
@@ -251,6 +252,12 @@ def main():
         # at 55-57 G requests/s on this chip (two-choice cuckoo experiment on c2; c5, whose index lives in HBM, sits there).
         "secondary_roofline": ({"bound": "l2_miss_requests", "achieved": miss_requests / avg_kernel_s / 1e9, "peak": 56.0, "unit": "G requests/s",
                                 "frac": miss_requests / avg_kernel_s / 1e9 / 56.0, "misses_per_read": miss_requests / n} if miss_requests else None),
+        # what binds the kernel (profiles/r01_tuning_notes.md): instruction issue. Instructions issued per read (SQ counters of the
+        # committed PMC pass) against the issue slots a SIMD has per read at this occupancy: above 1.0 = ports saturated.
+        "issue": ({"instructions_per_read": sq["SQ_ACTIVE_INST_ANY"], "valu": sq["SQ_INSTS_VALU"], "salu": sq["SQ_INSTS_SALU"], "vmem": sq["SQ_INSTS_VMEM"],
+                   "simd_slots_per_read": sq["SQ_WAVE_CYCLES"] / sq["waves_per_simd"],
+                   "issue_utilisation": sq["SQ_ACTIVE_INST_ANY"] / (sq["SQ_WAVE_CYCLES"] / sq["waves_per_simd"]),
+                   "wait_for_issue_frac": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"], "source": traffic_src} if sq else None),
         "cpu_baseline": cpu,
         "parity_sample_ok": parity,
         "index": {"kmers": stats["n_kmers"], "colours": stats["n_colours"], "table_MB": stats["table_slots"] * 16 / 1e6,
