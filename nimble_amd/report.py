@@ -12,7 +12,9 @@ Deviation (documented, tested): when every row ends up filtered the reference ra
 implementation writes the same empty output the reference writes for empty input (write_empty_df, __main__.py:299-302).
 """
 import csv
+import gzip
 import os
+import re
 
 import numpy as np
 
@@ -147,8 +149,9 @@ def report_native(input, output, threshold=0.05, disable_thresholding=False):
     _lib.check(_lib.lib().nb_report_tsv(os.fsencode(input), os.fsencode(output), float(threshold), int(bool(disable_thresholding)), st))
     if st[0]:
         print("No data to parse from input file, writing empty output.")
-    else:
-        print(f"Dropped {st[1]} UMIs due to empty intersections")
+        return False
+    print(f"Dropped {st[1]} UMIs due to empty intersections")
+    return True
 
 
 def report_rows(cb_ids, umi_keys, feat_ids, scores, cb_strings, feat_strings, output, threshold=0.05, disable_thresholding=False):
@@ -170,14 +173,103 @@ def report_rows(cb_ids, umi_keys, feat_ids, scores, cb_strings, feat_strings, ou
         print(f"Dropped {st[1]} UMIs due to empty intersections")
 
 
+_INT_RE = re.compile(r"[+-]?\d+\Z")
+_TRUE, _FALSE = {"True", "TRUE", "true"}, {"False", "FALSE", "false"}
+
+
+def _column_kind(values):
+    """The dtype pandas' parser gives a column (None = missing cell): 'int', 'float', 'bool' or 'object'."""
+    present = [v for v in values if v is not None]
+    if not present:
+        return "float"
+    if all(_INT_RE.match(v) for v in present):
+        return "int" if len(present) == len(values) else "float"      # a missing cell turns an integer column into floats
+    try:
+        for v in present:
+            float(v)
+        return "float"
+    except ValueError:
+        pass
+    if len(present) == len(values) and all(v in _TRUE or v in _FALSE for v in present):
+        return "bool"
+    return "object"
+
+
+def _column_key(kind, v):
+    """(hashable key, text as pandas prints it inside an f-string) of one cell."""
+    if kind == "int":
+        return int(v), str(int(v))
+    if kind == "float":
+        x = float(v)
+        return x, repr(x)
+    if kind == "bool":
+        return v in _TRUE, str(v in _TRUE)
+    return v, v
+
+
+def summarize_fields(input, columns, output_file):
+    """`report -s col1,col2`: per UMI, the values of the named columns of the per-read table with their frequencies,
+    "value(count); value(count)" by descending count (summarize_fields, /root/reference/nimble/__main__.py:307-310, applied to
+    the table with r1_CB / r1_UB / nimble_features renamed to cb / umi / features, :236). Restated without pandas: column
+    types as pandas' reader infers them (integers print bare, an integer column with a missing cell prints as floats), values
+    in order of first appearance, then the same descending sort pandas' value_counts applies; UMI groups in sorted order, rows
+    without a UMI left out. Held to outputs of the reference (tests/golden/summarize_cases.json)."""
+    opener = gzip.open if str(input).endswith(".gz") else open
+    with opener(input, "rt", newline="") as f:
+        lines = f.read().split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    rename = {"r1_CB": "cb", "r1_UB": "umi", "nimble_features": "features"}
+    header = [rename.get(h, h) for h in lines[0].rstrip("\r").split("\t")]
+    for c in ["umi"] + list(columns):
+        if c not in header:
+            raise KeyError(c)
+    want = [header.index(c) for c in ["umi"] + list(columns)]
+    table = []
+    for line in lines[1:]:
+        line = line.rstrip("\r")
+        if line == "":
+            continue                                      # pandas skips blank lines
+        cells = line.split("\t")
+        cells += [""] * (len(header) - len(cells))
+        table.append([None if cells[j] in _NA else cells[j] for j in want])
+    kinds = [_column_kind([row[j] for row in table]) for j in range(len(want))]
+    groups = {}
+    for row in table:
+        if row[0] is None:
+            continue
+        key, text = _column_key(kinds[0], row[0])
+        groups.setdefault(key, (text, []))[1].append(row)
+    with open(output_file, "w", newline="") as f:
+        w = csv.writer(f, delimiter="\t", quoting=csv.QUOTE_MINIMAL, lineterminator="\n")
+        w.writerow(["umi"] + list(columns))
+        for key in sorted(groups):
+            text, rows = groups[key]
+            out = [text]
+            for j in range(1, len(want)):
+                counts, texts = {}, {}
+                for row in rows:
+                    if row[j] is None:
+                        continue
+                    k, t = _column_key(kinds[j], row[j])
+                    counts[k] = counts.get(k, 0) + 1
+                    texts.setdefault(k, t)
+                keys = list(counts)
+                c = np.array([counts[k] for k in keys], dtype=np.int64)
+                # Series.sort_values(ascending=False) as pandas does it: argsort of the reversed array, reversed back
+                order = np.arange(len(keys))[::-1][c[::-1].argsort(kind="quicksort")][::-1] if keys else []
+                out.append("; ".join(f"{texts[keys[i]]}({counts[keys[i]]})" for i in order))
+            w.writerow(out)
+
+
 def report(input, output, summarize_columns_list=None, threshold=0.05, disable_thresholding=False, engine=None):
     """Same signature and output as the reference's report() (__main__.py:254). `engine`: "python" (this module) or
     "native" (nb_report_tsv); default from $NIMBLE_REPORT_ENGINE, else native. Both are pinned by the same fixtures."""
     engine = engine or os.environ.get("NIMBLE_REPORT_ENGINE", "native")
-    if summarize_columns_list:
-        raise NotImplementedError("report -s/--summarize (reference __main__.py:307-310) is outside the hot-path scope of this build")
     if engine == "native":
-        return report_native(input, output, threshold, disable_thresholding)
+        if report_native(input, output, threshold, disable_thresholding) and summarize_columns_list:
+            summarize_fields(input, summarize_columns_list, "summarize." + output)
+        return
     rows = read_rows(input)
     if rows is None:
         write_empty(output)
@@ -221,4 +313,4 @@ def report(input, output, summarize_columns_list=None, threshold=0.05, disable_t
         for cb, feat in sorted(counts):
             w.writerow([feat, counts[(cb, feat)], cb])
     if summarize_columns_list:
-        raise NotImplementedError("report -s/--summarize (reference __main__.py:307-310) is outside the hot-path scope of this build")
+        summarize_fields(input, summarize_columns_list, "summarize." + output)   # (the reference's naming, __main__.py:300)

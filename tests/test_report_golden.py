@@ -109,3 +109,22 @@ def test_native_report_threaded_equals_single_thread_and_python(variant, tmp_pat
         for name in ("bgzf.tsv.gz", "plain.tsv.gz"):
             rep.report(str(tmp_path / name), str(tmp_path / "gz_out.tsv"), engine="native")
             assert open(tmp_path / "gz_out.tsv").read() == outs["1"], name
+
+
+_SUMMARIZE = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "summarize_cases.json")))
+
+
+@pytest.mark.parametrize("idx", range(len(_SUMMARIZE)))
+@pytest.mark.parametrize("engine", ["python", "native"])
+def test_report_summarize_case(idx, engine, tmp_path, built, monkeypatch):
+    """`report -s cols`: the per-UMI value/frequency table of the reference's summarize_fields (__main__.py:307-310) — outputs of
+    the reference itself, incl. its column typing (ints / floats / bools / strings), tie order and quoting."""
+    case = _SUMMARIZE[idx]
+    (tmp_path / "in.tsv").write_text(case["input"])
+    monkeypatch.chdir(tmp_path)                            # "summarize." + output: the reference's naming needs a bare file name
+    if isinstance(case["output"], dict):
+        with pytest.raises(Exception):
+            rep.report("in.tsv", "out.tsv", case["columns"], engine=engine)
+        return
+    rep.report("in.tsv", "out.tsv", case["columns"], engine=engine)
+    assert open("summarize.out.tsv").read() == case["output"], case["name"]
