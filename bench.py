@@ -153,7 +153,7 @@ def main():
         t0 = time.time()
         oix = oracle.OracleIndex(strs, args.k)
         t_oidx = time.time() - t0
-        ns = min(args.parity_sample, n)
+        ns = min(args.parity_sample, n, first_codes.shape[0])     # (the generator hands back codes of its first chunk only)
         if ns:
             blob, off = synth.reads_to_ascii(first_codes[:ns])
             ora = oix.align(cfg, blob, off, n_threads=os.cpu_count() or 1)
@@ -165,7 +165,7 @@ def main():
             parity = bool((sets == ora["set_bits"]).all() and (info["score"] == ora["score"]).all()
                           and (info["reason"] == ora["reason"]).all() and (info["orientation"] == ora["orientation"]).all())
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample:
-            nc = min(args.cpu_sample, n)
+            nc = min(args.cpu_sample, n, first_codes.shape[0])
             cores = os.cpu_count() or 1
             blob, off = synth.reads_to_ascii(first_codes[:nc])
             t0 = time.perf_counter()
