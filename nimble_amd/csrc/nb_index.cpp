@@ -6,6 +6,7 @@
 // array is sorted, and colours / extension masks fall out of a single grouped pass. The result is the flat
 // canonical-k-mer table the kernels probe plus the colour bitset rows.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <unordered_map>
@@ -42,6 +43,22 @@ inline uint64_t mix64(uint64_t z) {
   z ^= z >> 33; z *= 0xff51afd7ed558ccdull; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull; z ^= z >> 33; return z;
 }
 
+int index_threads() {
+  int t = (int)std::thread::hardware_concurrency();
+  if (const char* e = std::getenv("NB_INDEX_THREADS")) t = std::atoi(e);
+  return std::max(1, std::min(t, 16));
+}
+
+template <class F>
+void parallel_ranges(size_t n, int threads, F&& f) {   // f(lo, hi) over [0, n) cut into `threads` ranges
+  const int T = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n >> 16));
+  if (T <= 1) { f((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back([&f, n, t, T] { f(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T); });
+  f((size_t)0, n / (size_t)T);
+  for (auto& x : th) x.join();
+}
+
 const KRec* find_rec(const std::vector<KRec>& recs, uint64_t x) {
   auto it = std::lower_bound(recs.begin(), recs.end(), x, [](const KRec& r, uint64_t v) { return r.kmer < v; });
   return (it != recs.end() && it->kmer == x) ? &*it : nullptr;
@@ -75,7 +92,8 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     }
   }
   if (occ.empty()) { set_error("nb_index_build: library has no k-mer of length k"); return NB_ERR_INVALID; }
-  std::sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) { return a.kmer != b.kmer ? a.kmer < b.kmer : a.seq < b.seq; });
+  const int threads = index_threads();
+  parallel_sort(occ, threads, [](const Occ& a, const Occ& b) { return a.kmer != b.kmer ? a.kmer < b.kmer : a.seq < b.seq; });
 
   // 2. group by k-mer: merged exts, member list; intern member lists into temp colour ids
   std::vector<KRec> recs;
@@ -154,20 +172,22 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
   }
 
   // 4. unitig-interior flags (SPEC §2, local rule). recs is sorted by k-mer.
-  for (auto& r : recs) {
-    if (__builtin_popcount(r.rext) == 1) {
-      const uint64_t y = (r.kmer >> 2) | ((uint64_t)__builtin_ctz(r.rext) << top);
-      const KRec* yr = find_rec(recs, y);
-      if (yr && __builtin_popcount(yr->lext) == 1 && yr->colour == r.colour && y != r.kmer) r.r_int = 1;
-    }
-  }
-  for (auto& r : recs) {
-    if (__builtin_popcount(r.lext) == 1) {
-      const uint64_t x = ((r.kmer << 2) | (uint64_t)__builtin_ctz(r.lext)) & mask;
-      const KRec* xr = find_rec(recs, x);
-      if (xr && xr->r_int) r.l_int = 1;
-    }
-  }
+  parallel_ranges(recs.size(), threads, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) { KRec& r = recs[i];
+      if (__builtin_popcount(r.rext) == 1) {
+        const uint64_t y = (r.kmer >> 2) | ((uint64_t)__builtin_ctz(r.rext) << top);
+        const KRec* yr = find_rec(recs, y);
+        if (yr && __builtin_popcount(yr->lext) == 1 && yr->colour == r.colour && y != r.kmer) r.r_int = 1;
+      } }
+  });
+  parallel_ranges(recs.size(), threads, [&](size_t lo, size_t hi) {   // (reads r_int of OTHER records: all of them are final by now)
+    for (size_t i = lo; i < hi; ++i) { KRec& r = recs[i];
+      if (__builtin_popcount(r.lext) == 1) {
+        const uint64_t x = ((r.kmer << 2) | (uint64_t)__builtin_ctz(r.lext)) & mask;
+        const KRec* xr = find_rec(recs, x);
+        if (xr && xr->r_int) r.l_int = 1;
+      } }
+  });
 
   // 5. canonical table: 32-byte buckets of two slots, load <= TABLE_MAX_LOAD (nb_internal.h).
   struct Canon { uint64_t key; uint32_t pay[2]; };
@@ -180,7 +200,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       tmp.push_back({canon, {(r.kmer != canon) ? 1 : 0, pay}});
       if (r.kmer == y) tmp.push_back({canon, {1, pay}});   // palindrome: both orientations are this k-mer
     }
-    std::sort(tmp.begin(), tmp.end());
+    parallel_sort(tmp, threads, [](const std::pair<uint64_t, std::pair<int, uint32_t>>& a, const std::pair<uint64_t, std::pair<int, uint32_t>>& b) { return a < b; });
     for (size_t i = 0; i < tmp.size();) {
       Canon c{tmp[i].first, {PAY_ABSENT, PAY_ABSENT}};
       size_t j = i;

@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "nimble_amd.h"
@@ -96,6 +98,32 @@ struct HostIndex {
   // device copies (owned by the ctx that uploaded; recorded here for stats)
   int uploaded = 0;
 };
+
+// sorted runs on worker threads, then rounds of pairwise merges (the keys are total orders, so the result is unique)
+template <class T, class Less>
+void parallel_sort(std::vector<T>& v, int threads, Less less) {
+  const size_t n = v.size();
+  int runs = 1; while (runs * 2 <= threads && n / (size_t)(runs * 2) >= ((size_t)1 << 16)) runs *= 2;
+  if (runs == 1) { std::sort(v.begin(), v.end(), less); return; }
+  std::vector<size_t> cut((size_t)runs + 1);
+  for (int r = 0; r <= runs; ++r) cut[(size_t)r] = n * (size_t)r / (size_t)runs;
+  { std::vector<std::thread> th;
+    for (int r = 0; r < runs; ++r) th.emplace_back([&, r] { std::sort(v.begin() + (std::ptrdiff_t)cut[(size_t)r], v.begin() + (std::ptrdiff_t)cut[(size_t)r + 1], less); });
+    for (auto& x : th) x.join(); }
+  std::vector<T> tmp(n);
+  std::vector<T>* src = &v; std::vector<T>* dst = &tmp;
+  for (int width = 1; width < runs; width *= 2) {
+    std::vector<std::thread> th;
+    for (int r = 0; r < runs; r += 2 * width)
+      th.emplace_back([&, r] {
+        const size_t lo = cut[(size_t)r], mid = cut[(size_t)std::min(r + width, runs)], hi = cut[(size_t)std::min(r + 2 * width, runs)];
+        std::merge(src->begin() + (std::ptrdiff_t)lo, src->begin() + (std::ptrdiff_t)mid, src->begin() + (std::ptrdiff_t)mid, src->begin() + (std::ptrdiff_t)hi,
+                   dst->begin() + (std::ptrdiff_t)lo, less); });
+    for (auto& x : th) x.join();
+    std::swap(src, dst);
+  }
+  if (src != &v) v.swap(tmp);
+}
 
 void set_error(const std::string& msg);
 int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, int k, HostIndex** out);

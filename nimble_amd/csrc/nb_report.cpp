@@ -127,32 +127,6 @@ int reducer_threads() {
   return std::max(1, std::min(threads, 32));
 }
 
-// sorted runs on worker threads, then rounds of pairwise merges (the keys are total orders, so the result is unique)
-template <class T, class Less>
-void parallel_sort(std::vector<T>& v, int threads, Less less) {
-  const size_t n = v.size();
-  int runs = 1; while (runs * 2 <= threads && n / (size_t)(runs * 2) >= ((size_t)1 << 16)) runs *= 2;
-  if (runs == 1) { std::sort(v.begin(), v.end(), less); return; }
-  std::vector<size_t> cut((size_t)runs + 1);
-  for (int r = 0; r <= runs; ++r) cut[(size_t)r] = n * (size_t)r / (size_t)runs;
-  { std::vector<std::thread> th;
-    for (int r = 0; r < runs; ++r) th.emplace_back([&, r] { std::sort(v.begin() + (std::ptrdiff_t)cut[(size_t)r], v.begin() + (std::ptrdiff_t)cut[(size_t)r + 1], less); });
-    for (auto& x : th) x.join(); }
-  std::vector<T> tmp(n);
-  std::vector<T>* src = &v; std::vector<T>* dst = &tmp;
-  for (int width = 1; width < runs; width *= 2) {
-    std::vector<std::thread> th;
-    for (int r = 0; r < runs; r += 2 * width)
-      th.emplace_back([&, r] {
-        const size_t lo = cut[(size_t)r], mid = cut[(size_t)std::min(r + width, runs)], hi = cut[(size_t)std::min(r + 2 * width, runs)];
-        std::merge(src->begin() + (std::ptrdiff_t)lo, src->begin() + (std::ptrdiff_t)mid, src->begin() + (std::ptrdiff_t)mid, src->begin() + (std::ptrdiff_t)hi,
-                   dst->begin() + (std::ptrdiff_t)lo, less); });
-    for (auto& x : th) x.join();
-    std::swap(src, dst);
-  }
-  if (src != &v) v.swap(tmp);
-}
-
 // The reduction proper, shared by the TSV and the array entry points. recs carry RANKS: cb / feat index cb_by_rank /
 // feat_by_rank (strings in lexicographic order), umi is any key that identifies the UMI (only grouping matters: the
 // output is ordered by (cell, feature) and integer scores do not depend on summation order; for float scores the TSV
@@ -175,7 +149,7 @@ int32_t reduce_records(std::vector<Rec>& recs, const std::vector<std::string>& c
     if (a.umi != b.umi) return a.umi < b.umi;
     if (a.feat != b.feat) return a.feat < b.feat;
     return a.seq < b.seq; };
-  parallel_sort(recs, reducer_threads(), rec_less);
+  nb::parallel_sort(recs, reducer_threads(), rec_less);
   struct Row { uint32_t cb; uint64_t umi; uint32_t feat; int64_t iscore; double fscore; };
   std::vector<Row> rows;
   rows.reserve(recs.size());
