@@ -647,15 +647,17 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
   {
     Tri HF, RF, LF, VF;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
-      const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
-      const bool hF = payF[r] != PAY_ABSENT;
-      F.col[r] = payF[r] >> 10;
-      HF.m[r] = __ballot(hF);
-      RF.m[r] = __ballot(hF && next_ok && ((payF[r] >> nextb) & 1u));
-      LF.m[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
-    }
+    for (int r = 0; r < 3; ++r) { F.col[r] = payF[r] >> 10; HF.m[r] = __ballot(payF[r] != PAY_ABSENT); }
+    if (HF.m[0] | HF.m[1] | HF.m[2]) {              // a read maps to one strand at most: the other one stops here
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
+        const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
+        const bool hF = payF[r] != PAY_ABSENT;
+        RF.m[r] = __ballot(hF && next_ok && ((payF[r] >> nextb) & 1u));
+        LF.m[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
+      }
+    } else { RF.m[0] = RF.m[1] = RF.m[2] = LF.m[0] = LF.m[1] = LF.m[2] = 0; }
     F.cov = (HF.m[0] | HF.m[1] | HF.m[2]) ? tri_walk(HF, RF, LF, L, K, kq, kr, VF) : 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) F.V.w[r] = F.cov ? VF.m[r] : 0ull;
@@ -663,15 +665,17 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
   {
     Tri HR, RR, LR, VR;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
-      const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
-      const bool hR = payR[r] != PAY_ABSENT;
-      R.col[r] = payR[r] >> 10;
-      HR.m[r] = __ballot(hR);
-      RR.m[r] = __ballot(hR && prev_ok && ((payR[r] >> (3u - prevb)) & 1u));
-      LR.m[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
-    }
+    for (int r = 0; r < 3; ++r) { R.col[r] = payR[r] >> 10; HR.m[r] = __ballot(payR[r] != PAY_ABSENT); }
+    if (HR.m[0] | HR.m[1] | HR.m[2]) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
+        const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
+        const bool hR = payR[r] != PAY_ABSENT;
+        RR.m[r] = __ballot(hR && prev_ok && ((payR[r] >> (3u - prevb)) & 1u));
+        LR.m[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
+      }
+    } else { RR.m[0] = RR.m[1] = RR.m[2] = LR.m[0] = LR.m[1] = LR.m[2] = 0; }
     R.cov = (HR.m[0] | HR.m[1] | HR.m[2]) ? tri_walk_down(HR, RR, LR, L, K, kq, kr, TPos{last / 3, last - 3 * (last / 3)}, VR) : 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) R.V.w[r] = R.cov ? VR.m[r] : 0ull;
