@@ -685,10 +685,10 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
 // Step 5: intern the set held in acc (lane-distributed) and return its dense class id, or NB_NO_CLASS on overflow.
 template <int TW>
 __device__ __forceinline__ uint32_t intern_class(const DevClasses& ct, int W, int lane, const uint64_t (&acc)[TW]) {
-  uint64_t hsum = 0;
+  uint64_t hx = 0;      // set hash: xor of one mixed word per (word index, value); every lane owns distinct word indices
 #pragma unroll
-  for (int t = 0; t < TW; ++t) if (acc[t]) hsum += mix64(acc[t] ^ (0x9E3779B97F4A7C15ull * (uint64_t)(64 * t + lane + 1)));
-  uint64_t key = wave_sum_u64(hsum);
+  for (int t = 0; t < TW; ++t) if (acc[t]) hx ^= mix64(acc[t] ^ (0x9E3779B97F4A7C15ull * (uint64_t)(64 * t + lane + 1)));
+  uint64_t key = wave_xor_u64(hx);
   if (key == 0) key = 1;
   const uint64_t smask = (1ull << ct.cap_log2) - 1;
   uint64_t h = (key * HASH_MULT) >> (64 - ct.cap_log2);

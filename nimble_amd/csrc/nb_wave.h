@@ -6,8 +6,10 @@
 namespace nb {
 
 // Wave-wide reductions with a wave-UNIFORM result: four DPP row rotations reduce inside each row of 16 lanes (every
-// lane of a row ends up with the row's value), then four v_readlane + scalar ops combine the rows. No LDS traffic
-// (ds_bpermute) and no lgkmcnt waits. Must be called with all 64 lanes active (wave-uniform control flow).
+// lane of a row ends up with the row's value); the rows are then folded with two DPP row broadcasts (row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 ends up with the total, one v_readlane) — or, for sums, with four
+// v_readlane + scalar adds. No LDS traffic (ds_bpermute) and no lgkmcnt waits. Must be called with all 64 lanes active
+// (wave-uniform control flow).
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
   // old = the source itself: with every lane enabled `old` is never selected, but passing 0 lets hipcc's DPP-combine fold
   // it into v_min_u32_dpp with a wrong identity (observed on ROCm 7.2: wave_min returned 0)
@@ -28,21 +30,22 @@ template <class OP> __device__ __forceinline__ uint32_t row_reduce(uint32_t v) {
   return v;
 }
 __device__ __forceinline__ uint32_t rows4(uint32_t v, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 16 * k); }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  v = row_reduce<OpMin>(v);
-  const uint32_t a = rows4(v, 0), b = rows4(v, 1), c = rows4(v, 2), d = rows4(v, 3);
-  const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
-  return ab < cd ? ab : cd;
+struct OpXor { __device__ __forceinline__ static uint32_t f(uint32_t a, uint32_t b) { return a ^ b; } };
+// rows folded by broadcasts; `old` = what a lane of a row that is masked out of a step receives. For the idempotent
+// operations that is the lane's own value (op(v, v) = v), for xor it is 0.
+template <class OP, bool IDEMPOTENT> __device__ __forceinline__ uint32_t wave_fold(uint32_t v) {
+  v = row_reduce<OP>(v);
+  uint32_t t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(IDEMPOTENT ? (int)v : 0, (int)v, 0x142, 0xA, 0xF, false); v = OP::f(v, t);   // row_bcast:15 -> rows 1, 3
+  t = (uint32_t)__builtin_amdgcn_update_dpp(IDEMPOTENT ? (int)v : 0, (int)v, 0x143, 0xC, 0xF, false); v = OP::f(v, t);   // row_bcast:31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-  v = row_reduce<OpMax>(v);
-  const uint32_t a = rows4(v, 0), b = rows4(v, 1), c = rows4(v, 2), d = rows4(v, 3);
-  const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-  return ab > cd ? ab : cd;
-}
-__device__ __forceinline__ uint32_t wave_and_u32(uint32_t v) {
-  v = row_reduce<OpAnd>(v);
-  return rows4(v, 0) & rows4(v, 1) & rows4(v, 2) & rows4(v, 3);
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return wave_fold<OpMin, true>(v); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return wave_fold<OpMax, true>(v); }
+__device__ __forceinline__ uint32_t wave_and_u32(uint32_t v) { return wave_fold<OpAnd, true>(v); }
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v) { return wave_fold<OpXor, false>(v); }
+__device__ __forceinline__ uint64_t wave_xor_u64(uint64_t v) {
+  return ((uint64_t)wave_xor_u32((uint32_t)(v >> 32)) << 32) | wave_xor_u32((uint32_t)v);
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   v = row_reduce<OpAdd>(v);
