@@ -52,9 +52,10 @@ constexpr uint64_t HASH_MULT = 0x9E3779B97F4A7C15ull;   // class-table hash (con
 #endif
 struct KmerHash { uint32_t mf, m1, n_buckets; };
 NB_HD inline uint32_t kmer_bucket(uint64_t canon, const KmerHash& h) {
-  uint32_t m = ((uint32_t)canon ^ ((uint32_t)(canon >> 32) * h.mf)) * h.m1;
-  m ^= m >> 15;
-  return (uint32_t)(((uint64_t)(m * 0x2C1B3C6Du) * (uint64_t)h.n_buckets) >> 32);
+  // two multiplicative hashes (the high bits of a product by an odd constant depend on every bit of the factor), xor-ed, then
+  // a multiply-high range reduction that reads exactly those high bits: 2 mul_lo + 1 mul_hi + 1 xor per k-mer on the device
+  const uint32_t m = ((uint32_t)canon * h.m1) ^ ((uint32_t)(canon >> 32) * h.mf);
+  return (uint32_t)(((uint64_t)m * (uint64_t)h.n_buckets) >> 32);
 }
 
 // A colour (equivalence class of the graph) on the device: the span of u64 words of its bitset that can be non-zero,
