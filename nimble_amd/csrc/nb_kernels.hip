@@ -306,18 +306,22 @@ __device__ __forceinline__ DescRegs load_desc(const DevIndex& ix, uint32_t colou
   DescRegs d; d.w0 = a.x; d.nw = a.y; d.off = a.z; d.m0 = ((uint64_t)b.y << 32) | b.x; d.m1 = ((uint64_t)b.w << 32) | b.z;
   return d;
 }
+// bit `lane` of a wave-UNIFORM 64-bit mask as a per-lane boolean: the mask's SGPR pair is used as the lane mask of a
+// v_cndmask directly (no shift / and / compare per test)
+__device__ __forceinline__ bool lane_bit(uint64_t uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
+
 // descriptors of this lane's positions on strand S; lanes/rounds without a hit read descriptor 0 (valid memory, unused)
 template <int NR>
 __device__ __forceinline__ void load_descs(const DevIndex& ix, const Strand<NR>& S, const Mask<NR>& hit, int lane, DescRegs (&d)[NR]) {
 #pragma unroll
-  for (int r = 0; r < NR; ++r) d[r] = load_desc(ix, ((hit.w[r] >> lane) & 1) ? S.col[r] : 0u);
+  for (int r = 0; r < NR; ++r) d[r] = load_desc(ix, lane_bit(hit.w[r]) ? S.col[r] : 0u);
 }
 
 template <int NR, int TW>
 __device__ __forceinline__ uint32_t intersect_descs(const DevIndex& ix, const Strand<NR>& S, const DescRegs (&d)[NR], int lane, uint64_t (&acc)[TW]) {
   uint32_t lo_l = 0u, hi_l = 0xFFFFFFFFu;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) if ((S.V.w[r] >> lane) & 1) { lo_l = d[r].w0 > lo_l ? d[r].w0 : lo_l; const uint32_t e = d[r].w0 + d[r].nw; hi_l = e < hi_l ? e : hi_l; }
+  for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { lo_l = d[r].w0 > lo_l ? d[r].w0 : lo_l; const uint32_t e = d[r].w0 + d[r].nw; hi_l = e < hi_l ? e : hi_l; }
   const uint32_t lo = wave_max_u32(lo_l), hi = wave_min_u32(hi_l);
 #pragma unroll
   for (int t = 0; t < TW; ++t) acc[t] = 0ull;
@@ -325,10 +329,10 @@ __device__ __forceinline__ uint32_t intersect_descs(const DevIndex& ix, const St
   for (uint32_t j = lo; j < hi; ++j) {            // wave-uniform; usually one or two words
     uint64_t v = ~0ull; bool need = false;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) if ((S.V.w[r] >> lane) & 1) { const uint32_t idx = j - d[r].w0; need |= idx >= 2u; v &= idx == 0u ? d[r].m0 : (idx == 1u ? d[r].m1 : ~0ull); }
+    for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { const uint32_t idx = j - d[r].w0; need |= idx >= 2u; v &= idx == 0u ? d[r].m0 : (idx == 1u ? d[r].m1 : ~0ull); }
     if (__ballot(need)) {                          // some class is wider than its two inline words here
 #pragma unroll
-      for (int r = 0; r < NR; ++r) if ((S.V.w[r] >> lane) & 1) { const uint32_t idx = j - d[r].w0; if (idx >= 2u) v &= ix.packed[(size_t)d[r].off + idx]; }
+      for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { const uint32_t idx = j - d[r].w0; if (idx >= 2u) v &= ix.packed[(size_t)d[r].off + idx]; }
     }
     v = wave_and_u64(v);
     n += (uint32_t)__popcll(v);
