@@ -415,7 +415,7 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
   if (__ballot(any_ovf)) {   // rare (load <= 0.10): some key overflowed its home bucket, follow the chain
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      uint32_t b = bk[r]; bool pending = ovf[r];
+      uint32_t b = kmer_bucket(canon[r], ix.hash); bool pending = ovf[r];
       while (pending) {
         b = (b + 1 == ix.hash.n_buckets) ? 0u : b + 1;
         uint32_t p0, p1; bool more;
@@ -584,7 +584,7 @@ __device__ __forceinline__ TriRec tri_load_record(const uint64_t* __restrict__ r
 // buckets, builds the masks, walks both strands and fills Strand<3> with w[r] / col[r] indexed by RESIDUE r.
 // (vmcnt retires in issue order: record loads issued BEFORE the bucket loads would make the bucket wait include the
 // HBM-cold record fetch; issued after, they overlap the mask/walk work.)
-struct TriProbe { uint64_t canon[3]; uint32_t bk[3]; uint32_t meta[3]; uint4 ka[3], kb[3]; };
+struct TriProbe { uint64_t canon[3]; uint32_t meta[3]; uint4 ka[3], kb[3]; };   // (the bucket index is recomputed on the rare overflow path: 3 VGPRs less)
 
 __device__ __forceinline__ void tri_issue(const DevIndex& ix, const TriRec& rec, int L, int lane, TriProbe& q) {
   const int K = ix.K, P = L - K + 1;
@@ -592,6 +592,7 @@ __device__ __forceinline__ void tri_issue(const DevIndex& ix, const TriRec& rec,
   const uint64_t W = rec.W, NW = rec.NW; const uint32_t prevb0 = rec.prevb0; const bool prevok0 = rec.prevok0;
   const uint64_t kmask = (1ull << (2 * K)) - 1, nkmask = (1ull << K) - 1;
   const uint64_t RCW = rc_kmer(W & ((1ull << (2 * (K + 2))) - 1), K + 2);   // one reverse complement for the three k-mers
+  uint32_t bk[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int i = i0 + r;
@@ -605,21 +606,24 @@ __device__ __forceinline__ void tri_issue(const DevIndex& ix, const TriRec& rec,
     const uint64_t c = x < y ? x : y;
     q.canon[r] = c;
 #if defined(NB_ABLATE) && NB_ABLATE >= 3
-    q.bk[r] = validk ? (kmer_bucket(c, ix.hash) & 1023u) : 0u;   // timing-only build: every lookup lands in 32 KB of the table
+    bk[r] = validk ? (kmer_bucket(c, ix.hash) & 1023u) : 0u;   // timing-only build: every lookup lands in 32 KB of the table
 #else
-    q.bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;
+    bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;
 #endif
     q.meta[r] = (validk ? 1u : 0u) | ((x != c) ? 2u : 0u) | (next_ok ? 4u : 0u) | (nextb << 3) | (prev_ok ? 32u : 0u) | (prevb << 6);
   }
   const Bucket* __restrict__ B = ix.buckets;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) { const uint4* kp = reinterpret_cast<const uint4*>(&B[q.bk[r]]); q.ka[r] = kp[0]; q.kb[r] = kp[1]; }
+  for (int r = 0; r < 3; ++r) { const uint4* kp = reinterpret_cast<const uint4*>(&B[bk[r]]); q.ka[r] = kp[0]; q.kb[r] = kp[1]; }
 }
 
-__device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q, int L, int lane, Strand<3>& F, Strand<3>& R) {
+// `lds` (or nullptr): this wave's six 64-lane rows of LDS. When given, the colour descriptors of the strand that has hits are
+// fetched straight into them (global_load_lds: no VGPR destination) as soon as the hit masks exist, so that their memory
+// round trip runs behind the scalar walk instead of after it. Returns which strand that was: 0 none, 1 read strand, 2 reverse.
+__device__ __forceinline__ int tri_finish(const DevIndex& ix, const TriProbe& q, int L, int lane, Strand<3>& F, Strand<3>& R, uint4 (*lds)[64] = nullptr) {
   const int K = ix.K;
   const Bucket* __restrict__ B = ix.buckets;
-  const uint64_t* canon = q.canon; const uint32_t* bk = q.bk; const uint32_t* meta = q.meta; const uint4* ka = q.ka; const uint4* kb = q.kb;
+  const uint64_t* canon = q.canon; const uint32_t* meta = q.meta; const uint4* ka = q.ka; const uint4* kb = q.kb;
   uint32_t payF[3], payR[3]; bool ovf[3]; bool any_ovf = false;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -636,7 +640,7 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
   if (__ballot(any_ovf)) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      uint32_t b = bk[r]; bool pending = ovf[r];
+      uint32_t b = kmer_bucket(canon[r], ix.hash); bool pending = ovf[r];   // (recomputed: only here is it needed after the loads)
       while (pending) {
         b = (b + 1 == ix.hash.n_buckets) ? 0u : b + 1;
         uint32_t p0, p1; bool more;
@@ -645,14 +649,28 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
       }
     }
   }
-  // The read strand is balloted and walked before the masks of the reverse strand exist: eighteen 64-bit masks at once do not
-  // fit the scalar register file next to the kernel arguments, and every spilled SGPR costs a v_writelane / v_readlane pair.
+  Tri HF, HR;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { F.col[r] = payF[r] >> 10; R.col[r] = payR[r] >> 10; HF.m[r] = __ballot(payF[r] != PAY_ABSENT); HR.m[r] = __ballot(payR[r] != PAY_ABSENT); }
+  const bool anyF = (HF.m[0] | HF.m[1] | HF.m[2]) != 0, anyR = (HR.m[0] | HR.m[1] | HR.m[2]) != 0;
+  int pre = 0;
+  if (lds && (anyF || anyR)) {
+    pre = anyF ? 1 : 2;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const uint32_t colour = lane_bit(anyF ? HF.m[r] : HR.m[r]) ? (anyF ? F.col[r] : R.col[r]) : 0u;
+      const char* g = reinterpret_cast<const char*>(&ix.desc[colour]);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[2 * r][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16), (__attribute__((address_space(3))) void*)&lds[2 * r + 1][0], 16, 0, 0);
+    }
+  }
+  // The read strand is balloted and walked before the extension masks of the reverse strand exist: eighteen 64-bit masks at
+  // once do not fit the scalar register file next to the kernel arguments, and every spilled SGPR costs a v_writelane /
+  // v_readlane pair. A read maps to one strand at most: the other one stops at its (empty) hit masks.
   const int kq = K / 3, kr = K - 3 * kq, last = L - K;
   {
-    Tri HF, RF, LF, VF;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { F.col[r] = payF[r] >> 10; HF.m[r] = __ballot(payF[r] != PAY_ABSENT); }
-    if (HF.m[0] | HF.m[1] | HF.m[2]) {              // a read maps to one strand at most: the other one stops here
+    Tri RF, LF, VF;
+    if (anyF) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
@@ -662,15 +680,13 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
         LF.m[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
       }
     } else { RF.m[0] = RF.m[1] = RF.m[2] = LF.m[0] = LF.m[1] = LF.m[2] = 0; }
-    F.cov = (HF.m[0] | HF.m[1] | HF.m[2]) ? tri_walk(HF, RF, LF, L, K, kq, kr, VF) : 0;
+    F.cov = anyF ? tri_walk(HF, RF, LF, L, K, kq, kr, VF) : 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) F.V.w[r] = F.cov ? VF.m[r] : 0ull;
   }
   {
-    Tri HR, RR, LR, VR;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { R.col[r] = payR[r] >> 10; HR.m[r] = __ballot(payR[r] != PAY_ABSENT); }
-    if (HR.m[0] | HR.m[1] | HR.m[2]) {
+    Tri RR, LR, VR;
+    if (anyR) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
@@ -680,10 +696,11 @@ __device__ __forceinline__ void tri_finish(const DevIndex& ix, const TriProbe& q
         LR.m[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
       }
     } else { RR.m[0] = RR.m[1] = RR.m[2] = LR.m[0] = LR.m[1] = LR.m[2] = 0; }
-    R.cov = (HR.m[0] | HR.m[1] | HR.m[2]) ? tri_walk_down(HR, RR, LR, L, K, kq, kr, TPos{last / 3, last - 3 * (last / 3)}, VR) : 0;
+    R.cov = anyR ? tri_walk_down(HR, RR, LR, L, K, kq, kr, TPos{last / 3, last - 3 * (last / 3)}, VR) : 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) R.V.w[r] = R.cov ? VR.m[r] : 0ull;
   }
+  return pre;
 }
 
 // Step 5: intern the set held in acc (lane-distributed) and return its dense class id, or NB_NO_CLASS on overflow.
@@ -763,6 +780,8 @@ __device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) 
 template <int NR, int TW, bool TRI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ctv, const DevClasses* __restrict__ ctp, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  constexpr bool LDS_DESC = TRI && TW == 1;   // (with wide class rows most descriptors point into `packed` anyway: measured a loss on c5)
+  __shared__ uint4 s_desc[LDS_DESC ? 4 : 1][LDS_DESC ? 6 : 1][LDS_DESC ? 64 : 1];   // per wave: 3 residues x 2 halves of a 32-byte descriptor per lane
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -797,11 +816,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
     if (TRI && L < ix.K) prefetch_next();
     if (L >= ix.K) {
       Strand<NR> SF, SR;
+      [[maybe_unused]] int pre = 0;                                          // strand whose descriptors wait in LDS (1 F, 2 R)
       if constexpr (TRI) {                                                  // 129..192 positions: three per lane
         TriProbe q;
         tri_issue(ix, rec, L, lane, q);
         prefetch_next();                              // this wave's next record, issued BEHIND the bucket loads
-        tri_finish(ix, q, L, lane, SF, SR);
+        if constexpr (LDS_DESC) pre = tri_finish(ix, q, L, lane, SF, SR, s_desc[wave]);
+        else pre = tri_finish(ix, q, L, lane, SF, SR);
       } else {
         const uint64_t* __restrict__ rp = reads_ro + (size_t)r * a.stride;   // separate noalias kernel argument: lets the
         map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR);           // compiler fetch the record with scalar loads
@@ -819,7 +840,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
 #if defined(NB_ABLATE) && NB_ABLATE >= 2
           acc[0] = (uint64_t)(isR ? SR.col[0] : SF.col[0]); const uint32_t n = 1;   // timing-only build: no intersection
 #else
-          const uint32_t n = isR ? intersect_visited<NR, TW>(ix, SR, lane, acc) : intersect_visited<NR, TW>(ix, SF, lane, acc);
+          uint32_t n;
+          bool from_lds = false;
+          if constexpr (LDS_DESC) from_lds = pre == (isR ? 2 : 1);
+          if (from_lds) {                               // descriptors fetched into LDS behind the walk (tri_finish)
+            DescRegs d[NR];
+            if constexpr (LDS_DESC) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+              for (int rr = 0; rr < NR; ++rr) {
+                const uint4 da = s_desc[wave][2 * rr][lane], db = s_desc[wave][2 * rr + 1][lane];
+                d[rr].w0 = da.x; d[rr].nw = da.y; d[rr].off = da.z; d[rr].m0 = ((uint64_t)db.y << 32) | db.x; d[rr].m1 = ((uint64_t)db.w << 32) | db.z;
+              }
+            }
+            n = isR ? intersect_descs<NR, TW>(ix, SR, d, lane, acc) : intersect_descs<NR, TW>(ix, SF, d, lane, acc);
+          } else n = isR ? intersect_visited<NR, TW>(ix, SR, lane, acc) : intersect_visited<NR, TW>(ix, SF, lane, acc);
 #endif
           if (n == 0) rs = NB_EMPTY_EQCLASS;
           else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
