@@ -127,7 +127,34 @@ int32_t nb_whitelist_correct(nb_whitelist* w, const char* raw, const char* qual,
     else {
       std::string r;
       if (w->set.count(key)) r = key;
-      else {
+      else if (w->fast_len == cb_len) {
+        // Hamming-1 candidates through the 2-bit table. A whitelist entry is ACGT only, so a raw barcode with one foreign
+        // character (N) can only be repaired at that position, and one with two or more not at all. Candidates are compared
+        // as the reference does: lowest quality at the differing base, ties to the lexicographically smallest string
+        // (= the smallest code: A < C < G < T, first base most significant).
+        const char* q = qual + i * cb_len;
+        int foreign = 0, fpos = -1; uint64_t code = 0;
+        for (int p = 0; p < cb_len; ++p) {
+          uint64_t c;
+          switch (key[(size_t)p]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = 0; ++foreign; fpos = p; }
+          code = (code << 2) | c;
+        }
+        if (foreign <= 1) {
+          int best_q = 1 << 30; uint64_t best_code = 0; bool any = false;
+          for (int p = (foreign ? fpos : 0); p < (foreign ? fpos + 1 : cb_len); ++p) {
+            const int sh = 2 * (cb_len - 1 - p);
+            const uint64_t cur = (code >> sh) & 3u;
+            for (uint64_t b = 0; b < 4; ++b) {
+              if (!foreign && b == cur) continue;
+              const uint64_t cand_code = (code & ~(3ull << sh)) | (b << sh);
+              if (!fast_contains(w, cand_code)) continue;
+              const int ql = (int)(unsigned char)q[p] - 33;
+              if (!any || ql < best_q || (ql == best_q && cand_code < best_code)) { any = true; best_q = ql; best_code = cand_code; }
+            }
+          }
+          if (any) { r.resize((size_t)cb_len); for (int p = 0; p < cb_len; ++p) r[(size_t)p] = "ACGT"[(best_code >> (2 * (cb_len - 1 - p))) & 3u]; }
+        }
+      } else {
         int n_cand = 0; int best_q = 1 << 30; best.clear();
         const char* q = qual + i * cb_len;
         for (int p = 0; p < cb_len; ++p)

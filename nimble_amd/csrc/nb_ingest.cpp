@@ -14,6 +14,9 @@
 //   3. the same workers pack the sequence lines 32 bases per word through a lookup table.
 #include <fcntl.h>
 #include <unistd.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
@@ -205,6 +208,19 @@ int32_t index_serial(nb_fastq* q, int64_t max_reads) {
   return NB_OK;
 }
 
+#if defined(__x86_64__)
+bool have_avx2() { static const bool ok = __builtin_cpu_supports("avx2"); return ok; }
+__attribute__((target("avx2"))) void newlines_avx2(const char* base, size_t lo, size_t hi, std::vector<size_t>& v) {
+  const __m256i nl = _mm256_set1_epi8('\n');
+  size_t i = lo;
+  for (; i + 32 <= hi; i += 32) {
+    uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(base + i)), nl));
+    while (m) { v.push_back(i + (size_t)__builtin_ctz(m)); m &= m - 1; }
+  }
+  for (; i < hi; ++i) if (base[i] == '\n') v.push_back(i);
+}
+#endif
+
 // parallel newline scan of buf[from, to): appends the offsets of '\n' to q->nl in order
 void scan_newlines(nb_fastq* q, size_t from, size_t to) {
   if (to <= from) return;
@@ -215,6 +231,9 @@ void scan_newlines(nb_fastq* q, size_t from, size_t to) {
     const size_t lo = from + (to - from) * (size_t)t / (size_t)T, hi = from + (to - from) * (size_t)(t + 1) / (size_t)T;
     auto& v = part[(size_t)t];
     v.reserve((hi - lo) / 64 + 16);
+#if defined(__x86_64__)
+    if (have_avx2()) { newlines_avx2(base, lo, hi, v); return; }   // (short lines: one memchr call per line costs more than the scan)
+#endif
     const char* p = base + lo; const char* e = base + hi;
     while (p < e) {
       const char* x = (const char*)std::memchr(p, '\n', (size_t)(e - p));
