@@ -651,19 +651,19 @@ __device__ __forceinline__ int tri_finish(const DevIndex& ix, const TriProbe& q,
   }
   Tri HF, HR;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) { F.col[r] = payF[r] >> 10; R.col[r] = payR[r] >> 10; HF.m[r] = __ballot(payF[r] != PAY_ABSENT); HR.m[r] = __ballot(payR[r] != PAY_ABSENT); }
-  const bool anyF = (HF.m[0] | HF.m[1] | HF.m[2]) != 0, anyR = (HR.m[0] | HR.m[1] | HR.m[2]) != 0;
+  for (int r = 0; r < 3; ++r) { F.col[r] = payF[r] >> 10; R.col[r] = payR[r] >> 10; HF.m[r] = __ballot(payF[r] != PAY_ABSENT); }
+  const bool anyF = (HF.m[0] | HF.m[1] | HF.m[2]) != 0;
   int pre = 0;
-  if (lds && (anyF || anyR)) {
-    pre = anyF ? 1 : 2;
+  auto fetch_descs = [&](const Tri& H, const uint32_t (&col)[3]) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const uint32_t colour = lane_bit(anyF ? HF.m[r] : HR.m[r]) ? (anyF ? F.col[r] : R.col[r]) : 0u;
+      const uint32_t colour = lane_bit(H.m[r]) ? col[r] : 0u;
       const char* g = reinterpret_cast<const char*>(&ix.desc[colour]);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[2 * r][0], 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16), (__attribute__((address_space(3))) void*)&lds[2 * r + 1][0], 16, 0, 0);
     }
-  }
+  };
+  if (lds && anyF) { pre = 1; fetch_descs(HF, F.col); }
   // The read strand is balloted and walked before the extension masks of the reverse strand exist: eighteen 64-bit masks at
   // once do not fit the scalar register file next to the kernel arguments, and every spilled SGPR costs a v_writelane /
   // v_readlane pair. A read maps to one strand at most: the other one stops at its (empty) hit masks.
@@ -686,6 +686,10 @@ __device__ __forceinline__ int tri_finish(const DevIndex& ix, const TriProbe& q,
   }
   {
     Tri RR, LR, VR;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) HR.m[r] = __ballot(payR[r] != PAY_ABSENT);      // (after the read strand's walk: fewer masks live at once)
+    const bool anyR = (HR.m[0] | HR.m[1] | HR.m[2]) != 0;
+    if (lds && !pre && anyR) { pre = 2; fetch_descs(HR, R.col); }
     if (anyR) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
