@@ -424,27 +424,47 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
       }
     }
   }
-  Mask<NR> HF, RF, LF, HR, RR, LR;
+  // one strand after the other (fewer masks live at once); a read maps to one strand at most, so the strand without hits
+  // stops at its empty hit mask and never builds its extension masks
+  {
+    Mask<NR> HF, RF, LF;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
-    const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
-    const bool hF = payF[r] != PAY_ABSENT, hR = payR[r] != PAY_ABSENT;
-    F.col[r] = payF[r] >> 10; R.col[r] = payR[r] >> 10;
-    HF.w[r] = __ballot(hF);
-    RF.w[r] = __ballot(hF && next_ok && ((payF[r] >> nextb) & 1u));
-    LF.w[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
-    HR.w[r] = __ballot(hR);
-    RR.w[r] = __ballot(hR && prev_ok && ((payR[r] >> (3u - prevb)) & 1u));
-    LR.w[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
+    for (int r = 0; r < NR; ++r) { F.col[r] = payF[r] >> 10; HF.w[r] = __ballot(payF[r] != PAY_ABSENT); }
+    if (any_set<NR>(HF)) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
+        const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
+        const bool hF = payF[r] != PAY_ABSENT;
+        RF.w[r] = __ballot(hF && next_ok && ((payF[r] >> nextb) & 1u));
+        LF.w[r] = __ballot(hF && prev_ok && ((payF[r] >> (4 + prevb)) & 1u));
+      }
+      F.cov = walk_masks<NR>(HF, RF, LF, L, K, F.V);
+    } else {
+      F.cov = 0;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) F.V.w[r] = 0;
+    }
   }
-  F.cov = any_set<NR>(HF) ? walk_masks<NR>(HF, RF, LF, L, K, F.V) : 0;
-  if (any_set<NR>(HR)) {
-    R.cov = walk_masks_down<NR>(HR, RR, LR, L, K, R.V);
-  } else {
-    R.cov = 0;
+  {
+    Mask<NR> HR, RR, LR;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) R.V.w[r] = 0;
+    for (int r = 0; r < NR; ++r) { R.col[r] = payR[r] >> 10; HR.w[r] = __ballot(payR[r] != PAY_ABSENT); }
+    if (any_set<NR>(HR)) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
+        const uint32_t nextb = (meta[r] >> 3) & 3u, prevb = (meta[r] >> 6) & 3u;
+        const bool hR = payR[r] != PAY_ABSENT;
+        RR.w[r] = __ballot(hR && prev_ok && ((payR[r] >> (3u - prevb)) & 1u));
+        LR.w[r] = __ballot(hR && next_ok && ((payR[r] >> (4 + (3u - nextb))) & 1u));
+      }
+      R.cov = walk_masks_down<NR>(HR, RR, LR, L, K, R.V);
+    } else {
+      R.cov = 0;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) R.V.w[r] = 0;
+    }
   }
 }
 
