@@ -355,8 +355,8 @@ __device__ __forceinline__ uint32_t intersect_visited(const DevIndex& ix, const 
 // trip for the lookups of a read), ballots build the masks and both strands are walked. The general kernel reaches the
 // same facts through position_facts(); tests hold both kernels to the oracle.
 template <int NR>
-__device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int lane,
-                                                      Strand<NR>& F, Strand<NR>& R) {
+__device__ __forceinline__ int map_both_strands_fast(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int lane,
+                                                     Strand<NR>& F, Strand<NR>& R, uint4 (*lds)[64] = nullptr) {
   constexpr int NWB = 2 * NR + 1, NWN = NR + 1;
   const int K = ix.K, P = L - K + 1, nwn = (nwb + 1) >> 1;
   uint64_t w[NWB + 1], nm[NWN + 1];
@@ -425,12 +425,24 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
     }
   }
   // one strand after the other (fewer masks live at once); a read maps to one strand at most, so the strand without hits
-  // stops at its empty hit mask and never builds its extension masks
+  // stops at its empty hit mask and never builds its extension masks. With `lds`, the colour descriptors of the strand that
+  // has hits go straight into this wave's LDS rows behind the walk (see tri_finish); returns that strand (0 none, 1 F, 2 R).
+  int pre = 0;
+  auto fetch_descs = [&](const Mask<NR>& H, const uint32_t (&col)[NR]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const uint32_t colour = lane_bit(H.w[r]) ? col[r] : 0u;
+      const char* g = reinterpret_cast<const char*>(&ix.desc[colour]);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[2 * r][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16), (__attribute__((address_space(3))) void*)&lds[2 * r + 1][0], 16, 0, 0);
+    }
+  };
   {
     Mask<NR> HF, RF, LF;
 #pragma unroll
     for (int r = 0; r < NR; ++r) { F.col[r] = payF[r] >> 10; HF.w[r] = __ballot(payF[r] != PAY_ABSENT); }
     if (any_set<NR>(HF)) {
+      if (lds) { pre = 1; fetch_descs(HF, F.col); }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
@@ -451,6 +463,7 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
 #pragma unroll
     for (int r = 0; r < NR; ++r) { R.col[r] = payR[r] >> 10; HR.w[r] = __ballot(payR[r] != PAY_ABSENT); }
     if (any_set<NR>(HR)) {
+      if (lds && !pre) { pre = 2; fetch_descs(HR, R.col); }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const bool next_ok = meta[r] & 4u, prev_ok = meta[r] & 32u;
@@ -466,6 +479,7 @@ __device__ __forceinline__ void map_both_strands_fast(const DevIndex& ix, const 
       for (int r = 0; r < NR; ++r) R.V.w[r] = 0;
     }
   }
+  return pre;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -804,8 +818,8 @@ __device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) 
 template <int NR, int TW, bool TRI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ctv, const DevClasses* __restrict__ ctp, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
-  constexpr bool LDS_DESC = TRI && TW == 1;   // (with wide class rows most descriptors point into `packed` anyway: measured a loss on c5)
-  __shared__ uint4 s_desc[LDS_DESC ? 4 : 1][LDS_DESC ? 6 : 1][LDS_DESC ? 64 : 1];   // per wave: 3 residues x 2 halves of a 32-byte descriptor per lane
+  constexpr bool LDS_DESC = TW == 1 && (TRI || NR == 2);   // (wide class rows go through `packed` anyway: a loss on c5; one round of positions: neutral)
+  __shared__ uint4 s_desc[LDS_DESC ? 4 : 1][LDS_DESC ? 2 * NR : 1][LDS_DESC ? 64 : 1];   // per wave: 3 residues x 2 halves of a 32-byte descriptor per lane
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -849,7 +863,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
         else pre = tri_finish(ix, q, L, lane, SF, SR);
       } else {
         const uint64_t* __restrict__ rp = reads_ro + (size_t)r * a.stride;   // separate noalias kernel argument: lets the
-        map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR);           // compiler fetch the record with scalar loads
+        if constexpr (LDS_DESC) pre = map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR, s_desc[wave]);   // compiler fetch the record
+        else map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR);                                          // with scalar loads
       }
       covF = SF.cov; covR = SR.cov;
       // candidates in preference order: larger coverage first, tie -> F   (SPEC §4 "Chosen orientation")
