@@ -201,20 +201,21 @@ def main():
         umi_id = (out_class.to(torch.int64) & 0xFFFFFFFF) * 64 + torch.randint(0, 64, (n,), generator=g, device=dev)
         cb_ids = (umi_id * 2654435761) % n_cells                          # a UMI belongs to one cell
         umi_codes = (umi_id * 40503) % (1 << 24)                          # 12-base UMI = 24 bits
-        # class -> feature string id on the host (names of the members; classes with > 10 features are rejected: max_hits_to_report)
-        bits = np.unpackbits(rows.view(np.uint8), axis=1, bitorder="little")
-        sizes = bits.sum(axis=1)
-        keep = np.nonzero((sizes > 0) & (sizes <= 10))[0]
-        ci, mi = np.nonzero(bits[keep])
-        feat_strings, cfid = [], np.full(rows.shape[0], -1, dtype=np.int64)
-        starts = np.searchsorted(ci, np.arange(keep.shape[0] + 1))
-        index_of = {}
-        for j, c in enumerate(keep):
-            key = ",".join(sorted(names[m] for m in mi[starts[j]:starts[j + 1]]))
-            fid = index_of.setdefault(key, len(feat_strings))
-            if fid == len(feat_strings):
-                feat_strings.append(key)
-            cfid[c] = fid
+        # class -> feature string id on the host (nb_class_features: names of the members; classes with > 10 features are rejected:
+        # max_hits_to_report)
+        import ctypes as ct
+        uniq = sorted(set(names))
+        fidx = {f: i for i, f in enumerate(uniq)}
+        enc = [f.encode() for f in uniq]
+        _, sorted_feats, creasons = engine.class_features(rows, np.array([fidx[f] for f in names], dtype=np.int32), (ct.c_char_p * len(enc))(*enc),
+                                                          len(enc), 10, 0, max(len(e) for e in enc))
+        feat_strings, cfid, index_of = [], np.full(rows.shape[0], -1, dtype=np.int64), {}
+        for c, (key, rs) in enumerate(zip(sorted_feats, creasons.tolist())):
+            if rs == 0 and key:
+                fid = index_of.setdefault(key, len(feat_strings))
+                if fid == len(feat_strings):
+                    feat_strings.append(key)
+                cfid[c] = fid
         t_map = time.perf_counter() - t0
         torch.cuda.synchronize(); t0 = time.perf_counter()
         cls_t = out_class.to(torch.int64) & 0xFFFFFFFF
