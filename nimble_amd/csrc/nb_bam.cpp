@@ -286,6 +286,7 @@ void pack_pending(nb_bam* b, int64_t count, int32_t len1, int32_t len2, uint64_t
 
 void compact(nb_bam* b) {
   if (b->have_pend || b->upos == 0) return;   // offsets of gathered templates must stay valid
+  if (b->upos < ((size_t)16 << 20) && b->upos < b->uend / 2) return;   // (amortised: a refill leaves ~32 MB behind uend; moving that per sub-batch would copy every byte five times)
   std::memmove(b->ubuf.data(), b->ubuf.data() + b->upos, b->uend - b->upos);
   b->uend -= b->upos; b->upos = 0;
 }
