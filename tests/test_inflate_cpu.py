@@ -148,3 +148,18 @@ def test_fastq_reader_on_gzip_equals_plain(built, tmp_path):
     assert len(got[0]) == len(got[1])
     for (m0, w0, l0), (m1, w1, l1) in zip(*got):
         assert m0 == m1 and (w0 == w1).all() and (l0 == l1).all()
+
+
+def test_sync_and_full_flush_markers(built, tmp_path, corpus):
+    """pigz-style streams: empty stored blocks (Z_SYNC_FLUSH / Z_FULL_FLUSH markers) between the compressed blocks, at odd bit
+    offsets; also a stream that ends in such a marker followed by an empty final block."""
+    data = corpus["fastq"] + corpus["runs"]
+    for flush in (zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = b""
+        for i in range(0, len(data), 7919):
+            body += c.compress(data[i:i + 7919]) + c.flush(flush)
+        body += c.flush()
+        p = tmp_path / "flush.gz"
+        p.write_bytes(b"\x1f\x8b\x08\x00" + b"\0" * 4 + b"\x00\x03" + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF))
+        assert gunzip(p, len(data) + 16) == data
