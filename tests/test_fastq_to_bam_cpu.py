@@ -48,7 +48,7 @@ def test_fastq_to_bam_matches_the_reference_rules(built, tmp_path, capsys):
     rng = np.random.default_rng(4)
     wl = sorted({"".join("ACGT"[c] for c in rng.integers(0, 4, 16)) for _ in range(500)})
     (tmp_path / "wl.txt").write_text("\n".join(wl) + "\n")
-    n = 30_000
+    n = 70_000                                             # more than one 65 536-pair sub-batch of the converter
     r1, r2 = [], []
     for i in range(n):
         cb = list(wl[int(rng.integers(0, len(wl)))])
