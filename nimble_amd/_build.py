@@ -30,13 +30,26 @@ def build(force=False, verbose=False):
     """Compile nimble_amd/csrc/* into nimble_amd/libnimble_amd.so for gfx950. hipcc cross-compiles without a GPU."""
     if not force and not needs_build():
         return LIB_PATH
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
-           "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH] + srcs + ["-lz"]
-    cmd[1:1] = os.environ.get("NB_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DNB_SE_WAVES_PER_EU=8 for tuning experiments
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    import fcntl
+    # several ranks of one job may get here together (torchrun, one process per GPU): one of them builds, the others wait
+    # for the lock and then find the library up to date. The output is written beside the target and renamed into place.
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB_PATH
+        srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+        tmp = LIB_PATH + f".{os.getpid()}.tmp"
+        cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+               "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC, "-o", tmp] + srcs + ["-lz"]
+        cmd[1:1] = os.environ.get("NB_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DNB_SE_WAVES_PER_EU=8 for tuning experiments
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        try:
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB_PATH
 
 
