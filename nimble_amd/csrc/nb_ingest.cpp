@@ -85,6 +85,8 @@ struct nb_fastq {
   // source + read-ahead thread
   int fd = -1;
   nb::GzipStream* gz = nullptr;
+  nb::BgzfReader* bgzf = nullptr;   // a gzip file made of BGZF blocks (bgzip): inflated block-parallel, like a BAM
+  FILE* bgzf_fp = nullptr;
   std::thread reader;
   std::mutex mu;
   std::condition_variable cv_data, cv_space;
@@ -121,7 +123,14 @@ struct nb_fastq {
         if (got < 0) err = std::string("gzip stream error: ") + (gz->error ? gz->error : "?");
         else c.n = (size_t)got;
       }
-      while (c.p && !gz && c.n < CHUNK_BYTES) {
+      while (c.p && bgzf && c.n + 65536 <= CHUNK_BYTES) {
+        bgzf->threads = threads;
+        const long got = bgzf->read((uint8_t*)c.p + CHUNK_PREFIX + c.n, CHUNK_BYTES - c.n);
+        if (got < 0) { err = std::string("gzip stream error: ") + (bgzf->error ? bgzf->error : "?"); break; }
+        if (got == 0) break;
+        c.n += (size_t)got;
+      }
+      while (c.p && !gz && !bgzf && c.n < CHUNK_BYTES) {
         const long got = (long)::read(fd, c.p + CHUNK_PREFIX + c.n, CHUNK_BYTES - c.n);
         if (got < 0) { err = "read error"; break; }
         if (got == 0) break;
@@ -129,7 +138,7 @@ struct nb_fastq {
       }
       std::unique_lock<std::mutex> lk(mu);
       if (!err.empty()) { src_error = err; src_done = true; std::free(c.p); cv_data.notify_all(); return; }
-      const bool last = c.n < CHUNK_BYTES;
+      const bool last = bgzf ? c.n + 65536 <= CHUNK_BYTES : c.n < CHUNK_BYTES;   // (a BGZF chunk stops when the next block might not fit)
       if (c.n) chunks.push_back(c); else std::free(c.p);
       if (last) src_done = true;
       cv_data.notify_all();
@@ -302,7 +311,12 @@ int32_t nb_fastq_open(const char* path, nb_fastq** out) {
   const long got = (long)::read(fd, magic, 2);
   ::lseek(fd, 0, SEEK_SET);
   nb_fastq* q = new nb_fastq();
-  if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+  unsigned char first[18]; const long got18 = (long)::pread(fd, first, 18, 0);
+  if (got18 == 18 && nb::BgzfReader::block_size(first, 18) > 0) {
+    q->bgzf_fp = ::fdopen(::dup(fd), "rb");
+    if (q->bgzf_fp) { q->bgzf = new nb::BgzfReader(); q->bgzf->fp = q->bgzf_fp; }
+  }
+  if (!q->bgzf && got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
     q->gz = new nb::GzipStream(); q->gz->fd = fd;
   }
   q->fd = fd;
@@ -323,6 +337,8 @@ int32_t nb_fastq_close(nb_fastq* q) {
   for (auto& c : q->chunks) std::free(c.p);
   for (char* p : q->spare) std::free(p);
   delete q->gz;
+  delete q->bgzf;
+  if (q->bgzf_fp) std::fclose(q->bgzf_fp);
   if (q->fd >= 0) ::close(q->fd);
   std::free(q->buf);
   delete q;

@@ -134,8 +134,10 @@ def test_fastq_reader_on_gzip_equals_plain(built, tmp_path):
     text = fastq_like(rng, 60_000)
     (tmp_path / "r.fastq").write_bytes(text)
     (tmp_path / "r.fastq.gz").write_bytes(raw_member(text[:1_000_000], 6) + raw_member(text[1_000_000:], 1))
+    from tests.helpers import _bgzf_block                      # bgzip-style FASTQ: inflated block-parallel, like a BAM
+    (tmp_path / "r.fastq.bgz").write_bytes(b"".join(_bgzf_block(text[i:i + 60000]) for i in range(0, len(text), 60000)) + _bgzf_block(b""))
     got = []
-    for name in ("r.fastq", "r.fastq.gz"):
+    for name in ("r.fastq", "r.fastq.gz", "r.fastq.bgz"):
         r = FastqReader(str(tmp_path / name), 3)
         rows = []
         while True:
@@ -145,9 +147,10 @@ def test_fastq_reader_on_gzip_equals_plain(built, tmp_path):
             rows.append((b["max_len"], b["words"].copy(), b["lens"].copy()))
         r.close()
         got.append(rows)
-    assert len(got[0]) == len(got[1])
-    for (m0, w0, l0), (m1, w1, l1) in zip(*got):
-        assert m0 == m1 and (w0 == w1).all() and (l0 == l1).all()
+    for other in got[1:]:
+        assert len(got[0]) == len(other)
+        for (m0, w0, l0), (m1, w1, l1) in zip(got[0], other):
+            assert m0 == m1 and (w0 == w1).all() and (l0 == l1).all()
 
 
 def test_sync_and_full_flush_markers(built, tmp_path, corpus):
