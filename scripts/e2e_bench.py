@@ -92,7 +92,31 @@ def main():
     rc = align(lib, os.path.join(d, "e2e_bulk_gz.tsv"), [fqz], cores, "unstranded", "", None)
     t = time.time() - t0
     print(f"[e2e] bulk single-end, gzip FASTQ: rc={rc} {ngz} reads in {t:.2f} s = {ngz / t / 1e6:.2f} M reads/s (gz {os.path.getsize(fqz) / 1e6:.0f} MB)")
-    for p in (fqz, os.path.join(d, "e2e_bulk_gz.tsv")):
+    # --- and as a BGZF file (bgzip): the same reader inflates its blocks in parallel ---
+    import ctypes as ct
+    from nimble_amd import _lib
+    fqb = os.path.join(d, "e2e_reads_bgzf.fastq.gz")
+    with open(fq, "rb") as src, open(fqb, "wb") as dst:
+        left = ngz * 4
+        piece = []
+        size = 0
+        def flush():
+            text = np.frombuffer(b"".join(piece), dtype=np.uint8)
+            cap = text.shape[0] + (text.shape[0] >> 9) + 64 * ((text.shape[0] >> 20) + 1) + 64
+            out, out_len = np.empty(cap, dtype=np.uint8), ct.c_int64()
+            _lib.check(_lib.lib().nb_gzip_members(text.ctypes.data, text.shape[0], 1, cores, out.ctypes.data, cap, ct.byref(out_len)))
+            dst.write(out[:out_len.value].tobytes())
+        for line in src:
+            piece.append(line); size += len(line); left -= 1
+            if size > (64 << 20) or left == 0:
+                flush(); piece, size = [], 0
+            if left == 0:
+                break
+    t0 = time.time()
+    rc = align(lib, os.path.join(d, "e2e_bulk_bgzf.tsv"), [fqb], cores, "unstranded", "", None)
+    t = time.time() - t0
+    print(f"[e2e] bulk single-end, BGZF FASTQ: rc={rc} {ngz} reads in {t:.2f} s = {ngz / t / 1e6:.2f} M reads/s (bgzf {os.path.getsize(fqb) / 1e6:.0f} MB)")
+    for p in (fqz, os.path.join(d, "e2e_bulk_gz.tsv"), fqb, os.path.join(d, "e2e_bulk_bgzf.tsv")):
         os.remove(p)
     # --- c3-like: 10x R1 barcodes + R2 91 bp ---
     rng = np.random.default_rng(3)
