@@ -85,6 +85,18 @@ int32_t nb_ctx_create(int32_t device_id, int64_t max_classes, nb_ctx** out);
 int32_t nb_ctx_destroy(nb_ctx* ctx);
 int32_t nb_ctx_sync(nb_ctx* ctx, void* stream);
 
+/* ---- device memory, streams, copies: so that a caller needs no GPU array library (PyTorch, hip-python ...) to drive
+ * nb_align_batch: INTEGRATION.md §B uses only these. Buffers from torch / any other allocator on the same device work as
+ * well (the hot call takes raw device pointers). `stream` = a stream from nb_stream_create, any hipStream_t, or NULL. ---- */
+int32_t nb_device_alloc(nb_ctx* ctx, int64_t bytes, void** d_out);
+int32_t nb_device_free(nb_ctx* ctx, void* d_ptr);
+int32_t nb_host_alloc_pinned(int64_t bytes, void** out);     /* page-locked host memory: async copies are true DMA */
+int32_t nb_host_free_pinned(void* ptr);
+int32_t nb_stream_create(nb_ctx* ctx, void** stream_out);
+int32_t nb_stream_destroy(nb_ctx* ctx, void* stream);
+int32_t nb_copy_h2d_async(nb_ctx* ctx, void* d_dst, const void* src, int64_t bytes, void* stream);
+int32_t nb_copy_d2h_async(nb_ctx* ctx, void* dst, const void* d_src, int64_t bytes, void* stream);
+
 /* ---- index: replaces the Rust binary's "-r LIB" load + graph build (__main__.py:182-189).
  * Built on the host from the library's `sequence` column (types.py:29-32, headers[3]); host-only, needs no GPU. ---- */
 int32_t nb_index_build(int32_t n_seqs, const char* const* seqs, const int64_t* seq_lens, int32_t k, nb_index** out);

@@ -43,6 +43,14 @@ SIGNATURES = {
     "nb_ctx_create": (ct.c_int32, [ct.c_int32, ct.c_int64, ct.POINTER(ct.c_void_p)]),
     "nb_ctx_destroy": (ct.c_int32, [ct.c_void_p]),
     "nb_ctx_sync": (ct.c_int32, [ct.c_void_p, ct.c_void_p]),
+    "nb_device_alloc": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.POINTER(ct.c_void_p)]),
+    "nb_device_free": (ct.c_int32, [ct.c_void_p, ct.c_void_p]),
+    "nb_host_alloc_pinned": (ct.c_int32, [ct.c_int64, ct.POINTER(ct.c_void_p)]),
+    "nb_host_free_pinned": (ct.c_int32, [ct.c_void_p]),
+    "nb_stream_create": (ct.c_int32, [ct.c_void_p, ct.POINTER(ct.c_void_p)]),
+    "nb_stream_destroy": (ct.c_int32, [ct.c_void_p, ct.c_void_p]),
+    "nb_copy_h2d_async": (ct.c_int32, [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_void_p]),
+    "nb_copy_d2h_async": (ct.c_int32, [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_void_p]),
     "nb_index_build": (ct.c_int32, [ct.c_int32, ct.POINTER(ct.c_char_p), c_i64p, ct.c_int32, ct.POINTER(ct.c_void_p)]),
     "nb_index_destroy": (ct.c_int32, [ct.c_void_p]),
     "nb_index_stats": (ct.c_int32, [ct.c_void_p, ct.POINTER(NbIndexStats)]),

@@ -24,7 +24,7 @@ import time
 import numpy as np
 
 from . import _lib, engine, fused
-from .library import Library
+from .library import Library, default_config
 from .utils import append_path_string, parse_trim
 
 BATCH_READS = int(os.environ.get("NB_BATCH_READS", 1 << 20))   # templates per GPU launch
@@ -51,7 +51,9 @@ def _host_buffer(shape, dtype, pinned):
 
 class FastqReader:
     """nb_fastq_* (csrc/nb_ingest.cpp). Batches alternate between two buffer sets: a returned batch stays valid until the
-    second next_batch() call after it (align() parses batch i+1 while batch i is on the GPU)."""
+    second next_batch() call after it (align() parses batch i+1 while batch i is on the GPU). A call with scratch=True
+    (the top-up of a batch that ended early, _top_up) reads into a third, private buffer set and does not advance the
+    turn, so it can never land in the buffers of the batch that is still being uploaded."""
 
     def __init__(self, path, threads=1, pinned=False):
         self._h = ct.c_void_p()
@@ -60,29 +62,31 @@ class FastqReader:
         self._pinned = pinned
         self._sets, self._turn = {}, 0
 
-    def _buffers(self, kind, max_reads, shape_tail, dtype):
-        key = (kind, self._turn & 1)
+    def _buffers(self, kind, max_reads, shape_tail, dtype, scratch=False):
+        key = (kind, "scratch" if scratch else self._turn & 1)
         buf = self._sets.get(key)
         if buf is None or buf.shape[0] < max_reads or buf.shape[1:] != tuple(shape_tail):
             buf = self._sets[key] = _host_buffer((max_reads,) + tuple(shape_tail), dtype, self._pinned)
         return buf
 
-    def next_batch(self, max_reads, max_len=None, barcodes_only=False, cb_len=0, umi_len=0):
+    def next_batch(self, max_reads, max_len=None, barcodes_only=False, cb_len=0, umi_len=0, scratch=False):
         """Returns dict(n, words, lens, max_len, cb, umi, cbq). The reads are packed at the layout of the batch's own longest
-        read (`max_len` in the result); the argument `max_len` is the longest read accepted."""
+        read (`max_len` in the result); the argument `max_len` is the longest read accepted. scratch=True: private buffers,
+        valid until the next scratch call only (the caller copies)."""
         n, batch_len = ct.c_int64(), ct.c_int32()
         L = _lib.lib()
-        self._turn += 1
+        if not scratch:
+            self._turn += 1
         if barcodes_only:
-            cb = self._buffers("cb", max_reads, (cb_len,), "S1")
-            umi = self._buffers("umi", max_reads, (umi_len,), "S1")
-            cbq = self._buffers("cbq", max_reads, (cb_len,), "S1")
+            cb = self._buffers("cb", max_reads, (cb_len,), "S1", scratch)
+            umi = self._buffers("umi", max_reads, (umi_len,), "S1", scratch)
+            cbq = self._buffers("cbq", max_reads, (cb_len,), "S1", scratch)
             _lib.check(L.nb_fastq_next_batch_tight(self._h, max_reads, 1, None, None, ct.byref(n), ct.byref(batch_len), cb.ctypes.data, cb_len,
                                                    umi.ctypes.data, umi_len, cbq.ctypes.data))
             k = n.value
             return {"n": k, "cb": cb[:k], "umi": umi[:k], "cbq": cbq[:k]}
-        flat = self._buffers("words", max_reads, (engine.packed_stride_words(max_len),), np.uint64).reshape(-1)
-        lens = self._buffers("lens", max_reads, (), np.uint16)
+        flat = self._buffers("words", max_reads, (engine.packed_stride_words(max_len),), np.uint64, scratch).reshape(-1)
+        lens = self._buffers("lens", max_reads, (), np.uint16, scratch)
         _lib.check(L.nb_fastq_next_batch_tight(self._h, max_reads, max_len, flat.ctypes.data, lens.ctypes.data, ct.byref(n), ct.byref(batch_len),
                                                None, 0, None, 0, None))
         k, stride = n.value, engine.packed_stride_words(max(batch_len.value, 1))
@@ -147,8 +151,8 @@ class BamReader:
 class LibraryRun:
     """One reference library on one GPU: index, context, class -> feature-string cache, output writer."""
 
-    def __init__(self, lib_path, out_path, strand_filter, device_id, per_read):
-        self.lib = Library(lib_path)
+    def __init__(self, lib, out_path, strand_filter, device_id, per_read):
+        self.lib = lib if isinstance(lib, Library) else Library(lib)
         c = self.lib.config
         self.cfg = engine.make_config(k=self.lib.k, score_threshold=c["score_threshold"], score_filter=c["score_filter"],
                                       score_percent=c["score_percent"], num_mismatches=c["num_mismatches"],
@@ -247,7 +251,7 @@ class LibraryRun:
 
 
 class NativeWhitelist:
-    """C++ whitelist corrector (csrc/nb_host.cpp); same rule as barcodes.BarcodeCorrector, batch at a time."""
+    """C++ whitelist corrector (csrc/nb_host.cpp); same rule as the Python twin tests/barcodes_twin.py, batch at a time."""
 
     def __init__(self, path, threads=1):
         self._h = ct.c_void_p()
@@ -317,7 +321,12 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         if strand_filter not in engine.STRAND_FILTERS:
             raise ValueError(f"--strand_filter must be one of {sorted(engine.STRAND_FILTERS)}")
         libs = reference.split(",")
-        parse_trim(trim, len(libs))
+        if parse_trim(trim, len(libs)) is not None:
+            _warn_not_honoured(f"--trim {trim!r}: reads are NOT trimmed by this engine (the rule lives in the Rust aligner only and is "
+                               "specified nowhere in the reference tree, docs/SPEC.md §5/§7); results are those of untrimmed reads")
+        loaded = [Library(lib) for lib in libs]
+        for lib in loaded:
+            _warn_library_options(lib)
         if not torch.cuda.is_available():
             raise RuntimeError("no MI355X/HIP device visible: nimble_amd has no CPU alignment path")
         dev = torch.device("cuda", device_id)
@@ -328,9 +337,9 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
             raise ValueError("tenx mode needs --input R1.fastq R2.fastq")
         paired = len(input) == 2 and not per_read   # (a paired BAM is detected from its flags, batch by batch)
         runs = []
-        for lib in libs:
+        for lib, loaded_lib in zip(libs, loaded):
             suffix = "." + os.path.splitext(os.path.basename(lib))[0] if len(libs) > 1 else ""
-            runs.append(LibraryRun(lib, append_path_string(output, suffix), strand_filter, device_id, per_read))
+            runs.append(LibraryRun(loaded_lib, append_path_string(output, suffix), strand_filter, device_id, per_read))
             runs[-1].gz_threads = max(1, int(num_cores))
             if report_output:
                 if not per_read:
@@ -461,6 +470,26 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         return 1
 
 
+def _warn_not_honoured(msg):
+    """One line on stderr for every option the reference's aligner honours and this engine does not (a drop-in must not
+    accept such an option silently; the exit code stays 0 because the run itself is valid for untrimmed / unfiltered input)."""
+    print(f"Warning -- not honoured: {msg}", file=sys.stderr)
+    sys.stderr.flush()
+
+
+def _warn_library_options(lib):
+    """Config fields of a library (types.py:20-25) that the Rust aligner reads and this engine does not act on."""
+    c, defaults = lib.config, default_config()
+    for key in ("trim_target_length", "trim_strictness"):
+        if c.get(key) != defaults[key]:
+            _warn_not_honoured(f"library {lib.stem}: {key} = {c.get(key)!r} (default {defaults[key]!r}): reads are NOT trimmed by this "
+                               "engine (docs/SPEC.md §5/§7)")
+    if c.get("filters"):
+        _warn_not_honoured(f"library {lib.stem}: filters = {c.get('filters')!r}: library filters are not applied (docs/SPEC.md §5/§7)")
+    if str(c.get("data_type", "RNA")) != "RNA":
+        _warn_not_honoured(f"library {lib.stem}: data_type = {c.get('data_type')!r}: has no effect in this engine (docs/SPEC.md §5/§7)")
+
+
 def _timed(prof, name, fn, *args):
     t = time.perf_counter()
     try:
@@ -499,7 +528,7 @@ def _top_up(reader, batch, want):
     parts = [{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()}]
     have = batch["n"]
     while have < want:
-        more = reader.next_batch(want - have, MAX_READ_LEN)
+        more = reader.next_batch(want - have, MAX_READ_LEN, scratch=True)   # never the buffers of the batch in flight
         if more["n"] == 0:
             raise ValueError("R1 and R2 FASTQ files have different numbers of records")
         parts.append({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in more.items()})

@@ -18,6 +18,7 @@
 #include <immintrin.h>
 #endif
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -99,7 +100,7 @@ struct nb_fastq {
   size_t cap = 0, pos = 0, end = 0, next_pos = 0;   // next_pos: where the indexed batch ends (pos moves there when it is packed)
   bool eof = false;
   int64_t record = 0;
-  int threads = 1;
+  std::atomic<int> threads{1};   // written by nb_fastq_set_threads after open, read by the read-ahead thread (BGZF inflate)
   // index of the current batch: offsets into buf
   std::vector<size_t> nl;
   std::vector<size_t> seq_b, seq_e, qual_b, qual_e;
@@ -124,7 +125,7 @@ struct nb_fastq {
         else c.n = (size_t)got;
       }
       while (c.p && bgzf && c.n + 65536 <= CHUNK_BYTES) {
-        bgzf->threads = threads;
+        bgzf->threads = threads.load(std::memory_order_relaxed);
         const long got = bgzf->read((uint8_t*)c.p + CHUNK_PREFIX + c.n, CHUNK_BYTES - c.n);
         if (got < 0) { err = std::string("gzip stream error: ") + (bgzf->error ? bgzf->error : "?"); break; }
         if (got == 0) break;
@@ -233,7 +234,7 @@ __attribute__((target("avx2"))) void newlines_avx2(const char* base, size_t lo, 
 // parallel newline scan of buf[from, to): appends the offsets of '\n' to q->nl in order
 void scan_newlines(nb_fastq* q, size_t from, size_t to) {
   if (to <= from) return;
-  const int T = (int)std::min<size_t>((size_t)q->threads, std::max<size_t>(1, (to - from) >> 20));
+  const int T = (int)std::min<size_t>((size_t)q->threads.load(), std::max<size_t>(1, (to - from) >> 20));
   std::vector<std::vector<size_t>> part((size_t)T);
   const char* base = q->buf;
   parallel_for(T, [&](int t) {
@@ -276,7 +277,7 @@ int index_fast(nb_fastq* q, int64_t max_reads) {
   if (n == 0) return q->end == 0 ? 1 : 0;   // nothing left at all, or a tail the serial walker must judge
   q->seq_b.resize((size_t)n); q->seq_e.resize((size_t)n); q->qual_b.resize((size_t)n); q->qual_e.resize((size_t)n);
   q->name_b.resize((size_t)n); q->name_e.resize((size_t)n);
-  const int T = (int)std::min<int64_t>(q->threads, std::max<int64_t>(1, n / 4096));
+  const int T = (int)std::min<int64_t>(q->threads.load(), std::max<int64_t>(1, n / 4096));
   std::vector<int> bad((size_t)T, 0);
   const char* base = q->buf; const size_t* nl = q->nl.data();
   parallel_for(T, [&](int t) {
@@ -400,7 +401,7 @@ int32_t nb_fastq_pack_batch(nb_fastq* q, int32_t max_len, uint64_t* out_words, u
   const int64_t n = q->n_indexed;
   const int nwb = (max_len + 31) / 32; const int64_t stride = out_words ? nb_packed_stride_words(max_len) : 0;
   const char* base = q->buf;
-  const int T = (int)std::min<int64_t>(q->threads, std::max<int64_t>(1, n / 4096));
+  const int T = (int)std::min<int64_t>(q->threads.load(), std::max<int64_t>(1, n / 4096));
   std::vector<int64_t> bad((size_t)T, -1); std::vector<int> bad_kind((size_t)T, 0);
   parallel_for(T, [&](int t) {
     const int64_t lo = n * t / T, hi = n * (t + 1) / T;

@@ -45,7 +45,7 @@ constexpr uint64_t HASH_MULT = 0x9E3779B97F4A7C15ull;   // class-table hash (con
 
 // bucket of a canonical k-mer: fold to 32 bits, one multiplicative mix, multiply-high range reduction
 // (3 x v_mul_lo_u32 + 1 x v_mul_hi_u32 on the GPU); n_buckets need not be a power of two.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)   // (nb_index.cpp may be built by a plain host compiler in the CPU sanitizer tests)
 #define NB_HD __host__ __device__
 #else
 #define NB_HD

@@ -1504,6 +1504,56 @@ int32_t nb_counts_device_ptr(nb_ctx* c, void** d_counts, int64_t* capacity) {
   *d_counts = c->ct.counts; *capacity = c->max_classes; return NB_OK;
 }
 
+// ---- device memory, streams and copies for callers without a GPU array library (INTEGRATION.md §B in plain ctypes / C) ----
+int32_t nb_device_alloc(nb_ctx* c, int64_t bytes, void** d_out) {
+  if (!c || !d_out || bytes < 0) { set_error("nb_device_alloc: bad arguments"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  *d_out = nullptr;
+  if (bytes) NB_HIP(hipMalloc(d_out, (size_t)bytes));
+  return NB_OK;
+}
+int32_t nb_device_free(nb_ctx* c, void* d) {
+  if (!c) { set_error("nb_device_free: null ctx"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  if (d) NB_HIP(hipFree(d));
+  return NB_OK;
+}
+int32_t nb_host_alloc_pinned(int64_t bytes, void** out) {
+  if (!out || bytes < 0) { set_error("nb_host_alloc_pinned: bad arguments"); return NB_ERR_INVALID; }
+  *out = nullptr;
+  if (bytes) NB_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  return NB_OK;
+}
+int32_t nb_host_free_pinned(void* p) {
+  if (p) NB_HIP(hipHostFree(p));
+  return NB_OK;
+}
+int32_t nb_stream_create(nb_ctx* c, void** stream_out) {
+  if (!c || !stream_out) { set_error("nb_stream_create: null argument"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  hipStream_t s = nullptr;
+  NB_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream_out = (void*)s; return NB_OK;
+}
+int32_t nb_stream_destroy(nb_ctx* c, void* stream) {
+  if (!c) { set_error("nb_stream_destroy: null ctx"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  if (stream) NB_HIP(hipStreamDestroy((hipStream_t)stream));
+  return NB_OK;
+}
+int32_t nb_copy_h2d_async(nb_ctx* c, void* d_dst, const void* src, int64_t bytes, void* stream) {
+  if (!c || bytes < 0 || (bytes && (!d_dst || !src))) { set_error("nb_copy_h2d_async: bad arguments"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  if (bytes) NB_HIP(hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return NB_OK;
+}
+int32_t nb_copy_d2h_async(nb_ctx* c, void* dst, const void* d_src, int64_t bytes, void* stream) {
+  if (!c || bytes < 0 || (bytes && (!dst || !d_src))) { set_error("nb_copy_d2h_async: bad arguments"); return NB_ERR_INVALID; }
+  NB_HIP(hipSetDevice(c->device));
+  if (bytes) NB_HIP(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return NB_OK;
+}
+
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired) {
   static thread_local char buf[96];
   const int positions = max_len - k + 1; const int nr = positions < 1 ? 1 : (positions + 63) / 64; const int W = (n_seqs + 63) / 64;

@@ -3,7 +3,7 @@
 Same signature, filters and printed statistics as fastq_to_bam_with_barcodes
 (/root/reference/nimble/fastq_barcode_processor.py:213-320); the work is done by nb_fastq_to_bam (csrc/nb_ingest.cpp): the
 FASTQ files are read with the engine's own readers (read-ahead, own inflater), barcodes corrected with nb_whitelist_correct
-(same rule as barcodes.BarcodeCorrector), records written as BGZF blocks compressed on `num_cores` threads. Differences,
+(same rule as the Python twin tests/barcodes_twin.py), records written as BGZF blocks compressed on `num_cores` threads. Differences,
 both deliberate: pairs are written in file order (the reference writes them in the completion order of its thread pool),
 and no pysam / Biopython is needed. `align` reads the result back like any BAM — or skips it: `align --tenx` takes the two
 FASTQ files directly."""

@@ -36,21 +36,48 @@ def decode_umi(code, w):
 
 def merge_rows(cb_ids, umi_codes, feat_ids, scores):
     """Sum the scores of identical (cb, umi, feature) rows. torch tensors on any device (int64). Returns the merged four
-    tensors. Two sort-based uniques: (cb, umi) pairs are dense-ranked first so that the second key fits 64 bits."""
+    tensors. Two sort-based uniques: (cb, umi) pairs are dense-ranked first so that the second key fits 64 bits. Ids too
+    wide for the packed pair key (more than 2^21 cell ids — raw barcodes without a whitelist — or interned UMI ids beyond
+    2^42) are dense-ranked per column first; if even the ranks do not fit, a three-key sort does the merge."""
     import torch
     if cb_ids.numel() == 0:
         return cb_ids, umi_codes, feat_ids, scores
+    if int(feat_ids.max()) >= (1 << 24):
+        raise ValueError("too many feature strings for the packed key")
+    ucb = uumi = None
     if int(umi_codes.max()) >= (1 << 42) or int(cb_ids.max()) >= (1 << 21):
-        raise ValueError("cell id / UMI code out of range for the packed key")
-    pair = (cb_ids << 42) | umi_codes
-    upair, inv = torch.unique(pair, return_inverse=True)
-    if int(feat_ids.max()) >= (1 << 24) or upair.numel() >= (1 << 39):
-        raise ValueError("too many feature strings / UMIs for the packed key")
-    key = (inv << 24) | feat_ids
-    ukey, inv2 = torch.unique(key, return_inverse=True)
-    summed = torch.zeros(ukey.numel(), dtype=torch.int64, device=key.device).index_add_(0, inv2, scores)
-    p = upair[ukey >> 24]
-    return p >> 42, p & ((1 << 42) - 1), ukey & ((1 << 24) - 1), summed
+        ucb, cb_ids = torch.unique(cb_ids, return_inverse=True)
+        uumi, umi_codes = torch.unique(umi_codes, return_inverse=True)
+    if ucb is not None and (ucb.numel() >= (1 << 21) or uumi.numel() >= (1 << 42)):
+        c, u, f, summed = _merge_wide(cb_ids, umi_codes, feat_ids, scores)
+    else:
+        pair = (cb_ids << 42) | umi_codes
+        upair, inv = torch.unique(pair, return_inverse=True)
+        if upair.numel() >= (1 << 39):
+            raise ValueError("too many UMIs for the packed key")
+        key = (inv << 24) | feat_ids
+        ukey, inv2 = torch.unique(key, return_inverse=True)
+        summed = torch.zeros(ukey.numel(), dtype=torch.int64, device=key.device).index_add_(0, inv2, scores)
+        p = upair[ukey >> 24]
+        c, u, f = p >> 42, p & ((1 << 42) - 1), ukey & ((1 << 24) - 1)
+    if ucb is not None:
+        c, u = ucb[c], uumi[u]
+    return c, u, f, summed
+
+
+def _merge_wide(cb_rank, umi_rank, feat_ids, scores):
+    """merge_rows for dense ranks whose product does not fit the 42-bit pair field: lexicographic sort on three keys (stable
+    sorts from the least significant key), then a segmented sum."""
+    import torch
+    order = torch.argsort(feat_ids, stable=True)
+    order = order[torch.argsort(umi_rank[order], stable=True)]
+    order = order[torch.argsort(cb_rank[order], stable=True)]
+    c, u, f, s = cb_rank[order], umi_rank[order], feat_ids[order], scores[order]
+    new = torch.ones(c.numel(), dtype=torch.bool, device=c.device)
+    new[1:] = (c[1:] != c[:-1]) | (u[1:] != u[:-1]) | (f[1:] != f[:-1])
+    seg = torch.cumsum(new.to(torch.int64), 0) - 1
+    summed = torch.zeros(int(seg[-1]) + 1, dtype=torch.int64, device=c.device).index_add_(0, seg, s)
+    return c[new], u[new], f[new], summed
 
 
 class RowAccumulator:

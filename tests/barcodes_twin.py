@@ -1,4 +1,5 @@
-"""10x cell-barcode whitelist correction (host). Restates /root/reference/nimble/fastq_barcode_processor.py:17-128.
+"""TEST TWIN (not product code; the product rule is C++: csrc/nb_host.cpp nb_whitelist_correct). 10x cell-barcode whitelist correction
+restated in Python from /root/reference/nimble/fastq_barcode_processor.py:17-128.
 
 Rule (correct_cell_barcode, :73-128): exact whitelist match -> keep; else the whitelist entries at Hamming distance 1;
 none -> the pair is dropped; one -> it; several -> the one whose differing base has the LOWEST phred quality in the raw

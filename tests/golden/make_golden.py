@@ -119,9 +119,72 @@ def run_summarize(m, text, columns):
             os.chdir(cwd)
 
 
+def reference_unit_vectors():
+    """The reference's OWN 24 reducer unit tests (test/test.py; CI runs only 11 of them because the second
+    `TestDataProcessing` class shadows the first) executed here with recording wrappers around
+    per_umi_thresholding / umi_intersection / intersect_lists: every call's input and returned value is dumped as data.
+    A recorded value is the test's expected vector whenever the test PASSES (its assertions compare exactly that value
+    with the hand-written expectation), and all 24 must pass for this function to return. Nothing but frames/lists of
+    strings and numbers is kept: no reference source text."""
+    import unittest
+    import pandas as pd
+    import nimble.utils as u
+    src = open("/root/reference/test/test.py").read()
+    first = src.index("class TestDataProcessing(")
+    second = src.index("class TestDataProcessing(", first + 1)
+    src = src[:second] + src[second:].replace("class TestDataProcessing(", "class TestDataProcessingSecond(", 1)   # un-shadow, in memory
+    ns = {"__name__": "reference_tests"}
+    exec(compile(src, "reference_tests", "exec"), ns)
+    calls, current = {}, [None]
+
+    def frame(df):
+        df = df.reset_index(drop=True)
+        return {"columns": [str(c) for c in df.columns],
+                "rows": [[(v if isinstance(v, (str, list)) else (None if pd.isna(v) else (int(v) if float(v).is_integer() and not isinstance(v, float) else float(v))))
+                          for v in row] for row in df.itertuples(index=False, name=None)]}
+
+    def wrap(name, fn):
+        def inner(*args, **kw):
+            if kw:                                   # (some tests pass threshold= by keyword)
+                args = args + tuple(kw[k] for k in ("threshold",) if k in kw)
+            rec = {"fn": name}
+            if name == "intersect_lists":
+                rec["input"] = [list(x) for x in args[0]]
+            else:
+                rec["input"] = frame(args[0].copy())
+                if name == "per_umi_thresholding":
+                    rec["threshold"] = float(args[1])
+            out = fn(*args)
+            rec["output"] = list(out) if name == "intersect_lists" else frame(out.copy())
+            calls.setdefault(current[0], []).append(rec)
+            return out
+        return inner
+
+    real_il = u.intersect_lists
+    ns["intersect_lists"] = wrap("intersect_lists", real_il)
+    ns["per_umi_thresholding"] = wrap("per_umi_thresholding", u.per_umi_thresholding)
+    ns["umi_intersection"] = wrap("umi_intersection", u.umi_intersection)      # (its inner intersect_lists calls are not recorded)
+    out = []
+    for cls in (ns["TestDataProcessing"], ns["TestDataProcessingSecond"]):
+        for meth in sorted(n for n in dir(cls) if n.startswith("test_")):
+            current[0] = meth
+            res = unittest.TestResult()
+            cls(meth).run(res)
+            if res.failures or res.errors:
+                raise RuntimeError(f"reference test {meth} did not pass here: {res.failures or res.errors}")
+            out.append({"test": meth, "ci_runs_it": cls is ns["TestDataProcessingSecond"], "calls": calls.get(meth, [])})
+    assert len(out) == 24, len(out)
+    return out
+
+
 def main():
     import nimble.__main__ as m
     import nimble.utils as u
+
+    # ---- the reference's own unit-test vectors (test/test.py, all 24) ----
+    uv = reference_unit_vectors()
+    json.dump(uv, open(os.path.join(OUT, "reference_unit_vectors.json"), "w"), indent=0)
+    print(f"reference unit tests: {len(uv)} passed, {sum(len(t['calls']) for t in uv)} recorded calls")
 
     # ---- report -s/--summarize (summarize_fields, nimble/__main__.py:307-310) ----
     sm = [{"name": name, "columns": cols, "input": text, "output": run_summarize(m, text, cols)} for name, cols, text in summarize_cases()]

@@ -149,7 +149,7 @@ def test_tenx_per_read_rows_then_report(built, tmp_path):
                 str(tmp_path / "R2.fastq.gz"), "--tenx", "--map", str(tmp_path / "wl.txt"), "--report-output", str(tmp_path / "fused.tsv"),
                 "--report-threshold", "0.1"]) == 0
     lib, ora = expected_bulk(lib_path, r2)
-    from nimble_amd import barcodes
+    from tests import barcodes_twin as barcodes
     corr = barcodes.BarcodeCorrector(set(wl))
     want = []
     for i in range(n):

@@ -7,7 +7,7 @@ import zlib
 
 import numpy as np
 
-from nimble_amd import barcodes
+from tests import barcodes_twin as barcodes
 from nimble_amd.__main__ import main as cli
 
 

@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from nimble_amd import barcodes, engine, library, synth, utils
+from nimble_amd import engine, library, synth, utils
+from tests import barcodes_twin as barcodes
 from nimble_amd.__main__ import build_parser
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -206,6 +207,28 @@ def test_align_without_gpu_returns_nonzero(built, tmp_path, capsys):
     assert align(str(tmp_path / "l.json"), str(tmp_path / "o.tsv"), ["x.bam"], 1, "unstranded", "", None) == 1
 
 
+def test_unsupported_options_are_announced(built, tmp_path, capsys):
+    """--trim, trim_* / filters / data_type of a library are read by the reference's aligner (nimble/__main__.py:191-192,
+    types.py:20-25) and not acted on here: align() must say so on stderr instead of accepting them silently. (The warnings
+    are printed before the device check, so this runs without a GPU.)"""
+    import json
+    from nimble_amd.align import align
+    fa = tmp_path / "l.fasta"; fa.write_text(">s\n" + "ACGT" * 20 + "\n")
+    library.generate(str(fa), None, str(tmp_path / "l.json"))
+    fq = tmp_path / "r.fastq"; fq.write_text("@r\n" + "ACGT" * 10 + "\n+\n" + "I" * 40 + "\n")
+    align(str(tmp_path / "l.json"), str(tmp_path / "o.tsv"), [str(fq)], 1, "unstranded", "", None)
+    assert "not honoured" not in capsys.readouterr().err            # defaults: nothing to announce
+    align(str(tmp_path / "l.json"), str(tmp_path / "o.tsv"), [str(fq)], 1, "unstranded", "40:0.8", None)
+    err = capsys.readouterr().err
+    assert "not honoured" in err and "--trim '40:0.8'" in err and "NOT trimmed" in err
+    doc = json.load(open(tmp_path / "l.json"))
+    doc[0].update(trim_target_length=30, filters=["x"], data_type="DNA")
+    json.dump(doc, open(tmp_path / "l2.json", "w"))
+    align(str(tmp_path / "l2.json"), str(tmp_path / "o.tsv"), [str(fq)], 1, "unstranded", "", None)
+    err = capsys.readouterr().err
+    assert err.count("not honoured") == 3 and "trim_target_length = 30" in err and "filters = ['x']" in err and "data_type = 'DNA'" in err
+
+
 def test_native_whitelist_matches_python_rule(built, tmp_path):
     """C++ corrector (nb_whitelist_correct) == barcodes.BarcodeCorrector on random barcodes incl. cache order effects."""
     from nimble_amd.align import NativeWhitelist
@@ -397,3 +420,57 @@ def test_fused_row_accumulator_equals_report_on_tsv(built, tmp_path):
     merged = acc.finish(None, feats, str(tmp_path / "got.tsv"), threshold=0.2)
     assert merged < n and open(tmp_path / "got.tsv").read() == open(tmp_path / "want.tsv").read()
     assert fused.decode_umi(fused.encode_umis(umi_arr[:1])[0], 12) == umis[ui[0]]
+
+
+def test_top_up_never_touches_the_batch_in_flight(built, tmp_path):
+    """A reader may end a batch early (before a longer read); align() then tops the batch up with further next_batch() calls
+    from the helper thread while the PREVIOUS batch is still being uploaded. Those extra calls must not land in the buffer
+    set of that previous batch (they did: the turn advanced once per call) — they read into private scratch buffers."""
+    from nimble_amd.align import FastqReader, _top_up
+    rng = np.random.default_rng(11)
+    n = 260_000
+    lens = rng.integers(20, 50, n)
+    lens[140_000] = 120                    # late long read: the second outer batch ends early in front of it
+    seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, L)) for L in lens]
+    p = tmp_path / "t.fastq"
+    p.write_text("".join(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(seqs)))
+    r = FastqReader(str(p), 2)
+    a = r.next_batch(100_000, 128)
+    assert a["n"] == 100_000
+    a_words, a_lens = a["words"].copy(), a["lens"].copy()
+    b = r.next_batch(100_000, 128)
+    assert 0 < b["n"] < 100_000            # ended early: the 120-base read needs a wider layout
+    full = _top_up(r, b, 100_000)
+    assert full["n"] == 100_000
+    assert (a["words"] == a_words).all() and (a["lens"] == a_lens).all()      # batch A (still "on its way to the GPU") is untouched
+    got = [engine.unpack_read(full["words"][i], int(full["lens"][i]), full["max_len"]) for i in range(0, 100_000, 997)]
+    assert got == [seqs[100_000 + i] for i in range(0, 100_000, 997)]
+    assert engine.unpack_read(full["words"][40_000], int(full["lens"][40_000]), full["max_len"]) == seqs[140_000]
+    c = r.next_batch(100_000, 128)         # the stream continues where the top-up stopped
+    assert c["n"] == 60_000 and engine.unpack_read(c["words"][0], int(c["lens"][0]), c["max_len"]) == seqs[200_000]
+    r.close()
+
+
+def test_fused_merge_rows_wide_ids():
+    """merge_rows with ids beyond the packed 21 + 42-bit pair key (e.g. > 2^21 raw cell barcodes without a whitelist):
+    dense ranks, and the three-key sort when even the ranks do not fit — same merged rows as a dictionary."""
+    import torch
+    from nimble_amd import fused
+    rng = np.random.default_rng(1)
+    n = 20000
+
+    def ref(cb, umi, f, s):
+        d = {}
+        for key in zip(cb.tolist(), umi.tolist(), f.tolist(), s.tolist()):
+            d[key[:3]] = d.get(key[:3], 0) + key[3]
+        return d
+    for cbmax, umimax in ((100, 1 << 24), (1 << 30, 1 << 24), (1 << 40, 1 << 50)):
+        cb = torch.from_numpy(rng.integers(0, cbmax, 300)[rng.integers(0, 300, n)])
+        umi = torch.from_numpy(rng.integers(0, umimax, 500)[rng.integers(0, 500, n)])
+        f, s = torch.from_numpy(rng.integers(0, 5, n)), torch.from_numpy(rng.integers(1, 3, n))
+        out = fused.merge_rows(cb, umi, f, s)
+        assert {k[:3]: k[3] for k in zip(*[x.tolist() for x in out])} == ref(cb, umi, f, s)
+    cb, umi = torch.from_numpy(rng.integers(0, 50, n)), torch.from_numpy(rng.integers(0, 60, n))
+    f, s = torch.from_numpy(rng.integers(0, 5, n)), torch.from_numpy(rng.integers(1, 3, n))
+    out = fused._merge_wide(cb, umi, f, s)
+    assert {k[:3]: k[3] for k in zip(*[x.tolist() for x in out])} == ref(cb, umi, f, s)
