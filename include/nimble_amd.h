@@ -29,7 +29,7 @@ extern "C" {
 #define NB_ERR_OVERFLOW (-4)    /* class table full: raise max_classes */
 #define NB_ERR_NOGPU (-5)       /* no usable HIP device */
 
-#define NB_ABI_VERSION 1
+#define NB_ABI_VERSION 2
 #define NB_MAX_K 31
 #define NB_MAX_POSITIONS 320    /* k-mer positions per read the kernels handle (5 wave-rounds of 64) */
 #define NB_NO_CLASS 0xFFFFFFFFu
@@ -65,13 +65,16 @@ typedef struct nb_config {
 typedef struct nb_index_stats_t {
   int64_t n_seqs;
   int64_t n_kmers;        /* distinct stranded k-mers (|S|) */
-  int64_t n_canonical;    /* occupied slots of the canonical-k-mer table */
-  int64_t table_slots;    /* capacity (power of two), 16 B each */
+  int64_t n_canonical;    /* distinct canonical k-mers */
+  int64_t table_slots;    /* entry capacity of the k-mer table */
+  int64_t table_bytes;    /* bytes of the k-mer table: 8-byte entries, (2,2) cuckoo (k <= 23) or 16-byte slots (k > 23) */
   int64_t n_colours;      /* equivalence classes of the graph */
   int64_t words_per_row;  /* u64 words per colour bitset = ceil(n_seqs/64) */
   int64_t device_bytes;   /* bytes the index occupies in HBM once uploaded */
   int32_t k;
   int32_t uploaded;
+  int32_t compact;        /* 1: compact cuckoo table (csrc/nb_internal.h), 0: wide table */
+  int32_t reserved;
 } nb_index_stats_t;
 
 typedef struct nb_ctx nb_ctx;

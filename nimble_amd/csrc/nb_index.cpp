@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <string>
 #include <unordered_map>
 
 #include "nb_internal.h"
@@ -209,6 +210,56 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     }
   }
   const int64_t n_canon = (int64_t)canons.size();
+  const char* force = std::getenv("NB_TABLE");       // "wide" forces the 16-byte-slot table (tests / A-B measurements), default = compact when k allows
+  if (k <= COMPACT_MAX_K && !(force && std::string(force) == "wide")) {
+    // 5a. compact table: (2,2) partial-key cuckoo, one entry per (canonical k-mer, strand) present (nb_internal.h)
+    int64_t n_entries = 0;
+    for (const Canon& c : canons) n_entries += (c.pay[0] != PAY_ABSENT) + (c.pay[1] != PAY_ABSENT);
+    const uint32_t hb = 2 * k > 32 ? (uint32_t)(2 * k - 32) : 0u;
+    const uint64_t nb_min = std::max<uint64_t>(256, 1ull << (hb + 2));
+    static const uint32_t MULS[4][2] = {{0x9E3779B1u, 0x85EBCA77u}, {0xC2B2AE3Du, 0x27D4EB2Fu}, {0x165667B1u, 0x9E3779B9u}, {0xD3A2646Du, 0xFD7046C5u}};
+    double load = COMPACT_LOAD;
+    bool done = false;
+    for (int attempt = 0; attempt < 12 && !done; ++attempt, load *= (attempt % 4 == 0 ? 0.93 : 1.0)) {
+      CHash h{}; h.a = MULS[attempt % 4][0]; h.c = MULS[attempt % 4][1]; h.hb = hb; h.himask = hb ? ((1u << hb) - 1u) : 0u;
+      uint64_t nb64 = std::max<uint64_t>(nb_min, (uint64_t)((double)n_entries / (2.0 * load)) + 1);
+      if (nb64 > 0x7FFFFFFFull) break;
+      h.nb = (uint32_t)nb64; h.nbm1 = h.nb - 1;
+      std::vector<CBucket> tab((size_t)nb64, CBucket{{{CKEY_EMPTY, PAY_ABSENT}, {CKEY_EMPTY, PAY_ABSENT}}});
+      uint64_t rng = 0x9E3779B97F4A7C15ull ^ (uint64_t)attempt;
+      bool ok = true;
+      auto place = [&](uint32_t key, uint32_t pay, uint32_t b) -> bool {      // random-walk insertion; key carries which/strand bits
+        for (int kick = 0; kick < 4000; ++kick) {
+          CBucket& bk = tab[b];
+          for (int j = 0; j < 2; ++j) if (bk.e[j].key == CKEY_EMPTY && bk.e[j].pay == PAY_ABSENT) { bk.e[j] = CEntry{key, pay}; return true; }
+          if (kick == 0 && !(key & 2u)) {                                      // first try the alternate bucket before evicting anyone
+            const uint32_t d = compact_alt_delta(key & ~3u, h); uint32_t b2 = b + d; if (b2 >= h.nb) b2 -= h.nb;
+            CBucket& alt = tab[b2];
+            for (int j = 0; j < 2; ++j) if (alt.e[j].key == CKEY_EMPTY && alt.e[j].pay == PAY_ABSENT) { alt.e[j] = CEntry{key | 2u, pay}; return true; }
+          }
+          rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+          const int j = (int)(rng >> 33) & 1;
+          std::swap(key, bk.e[j].key); std::swap(pay, bk.e[j].pay);            // evict entry j; the evicted one moves to ITS other bucket
+          const uint32_t d = compact_alt_delta(key & ~3u, h);
+          if (key & 2u) { b = b >= d ? b - d : b + h.nb - d; key &= ~2u; }     // was in its alternate bucket: back home
+          else { b += d; if (b >= h.nb) b -= h.nb; key |= 2u; }
+        }
+        return false;
+      };
+      for (const Canon& c : canons) {
+        const CProbe p = compact_probe(c.key, h);
+        for (int s = 0; s < 2 && ok; ++s) if (c.pay[s] != PAY_ABSENT) {
+          const uint32_t key = p.want | (uint32_t)s;
+          if (key == CKEY_EMPTY || (key | 2u) == CKEY_EMPTY) { ok = false; break; }   // would read as an empty entry: other multipliers
+          ok = place(key, c.pay[s], p.b1);
+        }
+        if (!ok) break;
+      }
+      if (ok) { ix->compact = true; ix->chash = h; ix->ctable.swap(tab); done = true; }
+    }
+    if (!done) { delete ix; set_error("nb_index_build: could not place the k-mers in the compact table"); return NB_ERR_UNSUPPORTED; }
+    ix->hash = KmerHash{0, 0, 0};
+  } else {
   uint64_t nb64 = (uint64_t)((double)n_canon / (SLOTS_PER_BUCKET * TABLE_MAX_LOAD)) + 1;
   if (nb64 < 256) nb64 = 256;
   if (nb64 > 0x7FFFFFFFull) { delete ix; set_error("nb_index_build: k-mer table would exceed 2^31 buckets"); return NB_ERR_UNSUPPORTED; }
@@ -224,6 +275,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       bk.slot[0].key |= KEY_OVERFLOW;                         // full: lookups of keys homed at or before b continue
       b = (b + 1 == ix->hash.n_buckets) ? 0 : b + 1;
     }
+  }
   }
   ix->n_canonical = n_canon;
   *out = ix;

@@ -58,6 +58,55 @@ NB_HD inline uint32_t kmer_bucket(uint64_t canon, const KmerHash& h) {
   return (uint32_t)(((uint64_t)m * (uint64_t)h.n_buckets) >> 32);
 }
 
+// ---- COMPACT table (k <= 23): the form the kernels use whenever the k-mer is short enough ----------------------------------
+// 16-byte buckets of TWO 8-byte entries {key word, payload}, (2,2) partial-key cuckoo hashing at load ~0.85: 9.4 bytes per stranded
+// k-mer instead of 160 (the 1 000-sequence library of BASELINE configs[1]: 2.9 MB instead of 49 MB, i.e. resident in every XCD's
+// 4 MiB L2; 50 sequences: 0.16 MB, which the kernels stage in LDS). A lookup reads BOTH candidate buckets with one dwordx4 each,
+// issued together: no probe loop, no overflow chain, no dependent load. Exactness without storing the k-mer:
+//   (hi, lo) = canonical k-mer split at bit 32           hb = max(2k - 32, 0) bits of hi
+//   m   = lo * a  ^  hi * c                               a odd: a bijection of lo for every hi
+//   hi2 = hi ^ ((m >> 7) & mask(hb))                      a bijection of hi for every m
+//   rem = m & (2^30 - 1)                                  stored in the entry
+//   g   = top 32 bits of the (hb + 32)-bit value hi2:m ;  b1 = mulhi(g, nb)        home bucket
+//   b2  = (b1 + 1 + mulhi(rem bit-reversed and left-aligned, nb - 1)) mod nb         alternate bucket, a function of (b1, rem) only
+// Two distinct k-mers with equal rem differ in the top hb + 2 bits of g, hence by >= 2^(30 - hb) in g, hence in b1 as soon as
+// nb >= 2^(hb + 2) (enforced): (b1, rem) identifies the k-mer. An entry records WHICH of its two buckets it sits in, and b1 =
+// b2 - d(rem) recovers the home bucket from the alternate one, so (bucket, rem, which) identifies it as well: a lookup that
+// compares rem and `which` in the two buckets can never match another k-mer — absent k-mers included.
+//   key word  bits [2,32) rem   bit 1 which (0 = home bucket, 1 = alternate)   bit 0 strand (0: the payload describes the k-mer
+//             equal to the canonical key as it occurs in the reference, 1: its reverse complement as it occurs)
+//   payload   as below (make_payload); an empty entry is {0xFFFFFFFF, PAY_ABSENT}; the builder re-seeds (a, c) if a real key
+//             word would equal 0xFFFFFFFF
+struct CEntry { uint32_t key, pay; };
+struct CBucket { CEntry e[2]; };
+static_assert(sizeof(CBucket) == 16, "compact bucket must be 16 bytes");
+constexpr int COMPACT_MAX_K = 23;                       // hb <= 14: nb >= 2^16 buckets (1 MiB) at the most
+constexpr double COMPACT_LOAD = 0.85;                   // (2,2) cuckoo threshold is 0.897
+constexpr uint32_t CKEY_EMPTY = 0xFFFFFFFFu;
+struct CHash { uint32_t a, c, nb, nbm1, hb, himask; };
+struct CProbe { uint32_t want, b1, b2; };               // want = rem << 2 (which = 0, strand = 0)
+NB_HD inline uint32_t nb_mulhi32(uint32_t x, uint32_t y) { return (uint32_t)(((uint64_t)x * (uint64_t)y) >> 32); }   // v_mul_hi_u32 on the device
+NB_HD inline uint32_t nb_brev32(uint32_t x) {
+#if defined(__clang__)
+  return __builtin_bitreverse32(x);                     // v_bfrev_b32 on the device
+#else
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4); x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+  return (x >> 16) | (x << 16);
+#endif
+}
+NB_HD inline uint32_t compact_alt_delta(uint32_t want, const CHash& h) { return 1u + nb_mulhi32(nb_brev32(want) << 2, h.nbm1); }   // in [1, nb - 1]; want = rem << 2
+NB_HD inline CProbe compact_probe(uint64_t canon, const CHash& h) {
+  const uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
+  const uint32_t m = (lo * h.a) ^ (hi * h.c);
+  const uint32_t hi2 = hi ^ ((m >> 7) & h.himask);
+  const uint32_t g = h.hb ? ((hi2 << (32u - h.hb)) | (m >> h.hb)) : m;
+  CProbe p; p.want = m << 2; p.b1 = nb_mulhi32(g, h.nb);
+  const uint32_t b2 = p.b1 + compact_alt_delta(p.want, h);
+  p.b2 = b2 >= h.nb ? b2 - h.nb : b2;
+  return p;
+}
+
 // A colour (equivalence class of the graph) on the device: the span of u64 words of its bitset that can be non-zero,
 // with the first two words inline. Most classes of a gene-family library live inside one locus, i.e. inside one or two
 // words, so the intersection of a read's classes usually needs nothing but these 32 bytes per k-mer position; wider
@@ -86,6 +135,9 @@ inline uint64_t rc_kmer_host(uint64_t x, int k) {
 
 struct HostIndex {
   int k = 20;
+  bool compact = false;               // true: ctable/chash are the table (k <= COMPACT_MAX_K); false: buckets/hash
+  CHash chash{};
+  std::vector<CBucket> ctable;        // chash.nb buckets
   int n_seqs = 0;
   int words = 0;                      // u64 words per colour row
   KmerHash hash{};                    // hash.n_buckets buckets of SLOTS_PER_BUCKET slots

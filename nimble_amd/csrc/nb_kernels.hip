@@ -30,13 +30,30 @@ namespace nb {
 // ------------------------------------------------------------------------------------------------------------
 // device-side views
 struct DevIndex {
-  const Bucket* buckets;  // hash.n_buckets 32-byte buckets (nb_internal.h)
+  const Bucket* buckets;  // wide table (k > COMPACT_MAX_K): hash.n_buckets 32-byte buckets (nb_internal.h)
+  const CBucket* ctable;  // compact table (k <= COMPACT_MAX_K): chash.nb 16-byte buckets; exactly one of the two is set
   const ColDesc* desc;    // n_colours colour descriptors (span + first two words)
   const uint64_t* packed; // spans of the colours wider than two words
   KmerHash hash;
+  CHash chash;
   int W;                  // u64 words per colour row
   int K;
 };
+
+// Compact table: both candidate buckets of a k-mer as they came back from memory (a = home, c = alternate; uint4 = {key0, pay0,
+// key1, pay1}) -> payload on the read strand (entry whose strand bit equals o = "the read's k-mer is the reverse complement of
+// the canonical key") and on the reverse-complement strand. Entries of the home bucket must carry which = 0, those of the
+// alternate bucket which = 1 (nb_internal.h: that is what makes the match exact). 8 compares + 8 selects, no loop.
+__device__ __forceinline__ void compact_match(const uint4& a, const uint4& c, uint32_t want, uint32_t o, bool valid, uint32_t& payF, uint32_t& payR) {
+  const uint32_t wF1 = want | o, wR1 = wF1 ^ 1u, wF2 = wF1 | 2u, wR2 = wR1 | 2u;
+  uint32_t f = PAY_ABSENT, r = PAY_ABSENT;
+  f = a.x == wF1 ? a.y : f; r = a.x == wR1 ? a.y : r;
+  f = a.z == wF1 ? a.w : f; r = a.z == wR1 ? a.w : r;
+  f = c.x == wF2 ? c.y : f; r = c.x == wR2 ? c.y : r;
+  f = c.z == wF2 ? c.w : f; r = c.z == wR2 ? c.w : r;
+  payF = valid ? f : PAY_ABSENT; payR = valid ? r : PAY_ABSENT;
+}
+__device__ __forceinline__ uint4 load_cbucket(const CBucket* __restrict__ T, uint32_t b) { return *reinterpret_cast<const uint4*>(&T[b]); }
 
 // One bucket probe for one lane. Returns true on a hit and fills p0/p1; `more` = the bucket is flagged OVERFLOW (the key
 // may live in the next bucket).
@@ -236,6 +253,7 @@ struct PosFacts {
   bool hF, rF, lF, hR, rR, lR;
 };
 
+template <bool CT>
 __device__ __forceinline__ PosFacts position_facts(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int i, bool active) {
   PosFacts f; f.payF = PAY_ABSENT; f.payR = PAY_ABSENT; f.hF = f.rF = f.lF = f.hR = f.rR = f.lR = false;
   if (!active) return f;
@@ -262,7 +280,11 @@ __device__ __forceinline__ PosFacts position_facts(const DevIndex& ix, const uin
   const uint64_t y = rc_kmer(x, K);
   const uint64_t canon = x < y ? x : y;
   const int o = (x != canon) ? 1 : 0;
-  {
+  if constexpr (CT) {
+    const CProbe p = compact_probe(canon, ix.chash);
+    const uint4 a = load_cbucket(ix.ctable, p.b1), c = load_cbucket(ix.ctable, p.b2);
+    compact_match(a, c, p.want, (uint32_t)o, true, f.payF, f.payR);
+  } else {
     uint32_t b = kmer_bucket(canon, ix.hash), p0 = PAY_ABSENT, p1 = PAY_ABSENT;
     for (;;) {
       bool more;
@@ -354,7 +376,7 @@ __device__ __forceinline__ uint32_t intersect_visited(const DevIndex& ix, const 
 // every round's k-mer is prepared, then the bucket loads of ALL rounds are issued together (one dependent memory round
 // trip for the lookups of a read), ballots build the masks and both strands are walked. The general kernel reaches the
 // same facts through position_facts(); tests hold both kernels to the oracle.
-template <int NR>
+template <int NR, bool CT>
 __device__ __forceinline__ int map_both_strands_fast(const DevIndex& ix, const uint64_t* __restrict__ rp, int nwb, int L, int lane,
                                                      Strand<NR>& F, Strand<NR>& R, uint4 (*lds)[64] = nullptr) {
   constexpr int NWB = 2 * NR + 1, NWN = NR + 1;
@@ -369,7 +391,7 @@ __device__ __forceinline__ int map_both_strands_fast(const DevIndex& ix, const u
   const bool hiHalf = lane >= 32;
   const int sh = (lane & 31) * 2;
   const uint64_t kmask = (1ull << (2 * K)) - 1, nkmask = (1ull << K) - 1;
-  uint64_t canon[NR]; uint32_t bk[NR]; uint32_t meta[NR];
+  uint64_t canon[CT ? 1 : NR]; uint32_t bk[NR]; uint32_t bk2[CT ? NR : 1]; uint32_t want[CT ? NR : 1]; uint32_t meta[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int i = lane + 64 * r;
@@ -389,17 +411,28 @@ __device__ __forceinline__ int map_both_strands_fast(const DevIndex& ix, const u
     const bool prev_ok = (i >= 1) && !prevN;
     const uint64_t y = rc_kmer(x, K);
     const uint64_t c = x < y ? x : y;
-    canon[r] = c;
-    bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;   // idle lanes read bucket 0: every load is unconditional, so the
-                                                      // key halves of all NR buckets of a read are in flight together
+    if constexpr (CT) {
+      const CProbe pr = compact_probe(c, ix.chash);
+      want[r] = pr.want; bk[r] = validk ? pr.b1 : 0u; bk2[r] = validk ? pr.b2 : 0u;
+    } else {
+      canon[r] = c;
+      bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;   // idle lanes read bucket 0: every load is unconditional, so the
+    }                                                   // key halves of all NR buckets of a read are in flight together
     meta[r] = (validk ? 1u : 0u) | ((x != c) ? 2u : 0u) | (next_ok ? 4u : 0u) | (nextb << 3) | (prev_ok ? 32u : 0u) | (prevb << 6);
   }
   // bucket lookup (nb_internal.h): both 16-byte slots of the home bucket, key and payload together
   const Bucket* __restrict__ B = ix.buckets;
   uint4 ka[NR], kb[NR];
+  uint32_t payF[NR], payR[NR];
+  if constexpr (CT) {   // compact table: home and alternate bucket, one dwordx4 each, all rounds in flight together; no chain to follow
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { ka[r] = load_cbucket(ix.ctable, bk[r]); kb[r] = load_cbucket(ix.ctable, bk2[r]); }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) compact_match(ka[r], kb[r], want[r], (meta[r] >> 1) & 1u, meta[r] & 1u, payF[r], payR[r]);
+  } else {
 #pragma unroll
   for (int r = 0; r < NR; ++r) { const uint4* kp = reinterpret_cast<const uint4*>(&B[bk[r]]); ka[r] = kp[0]; kb[r] = kp[1]; }
-  uint32_t payF[NR], payR[NR]; bool ovf[NR]; bool any_ovf = false;
+  bool ovf[NR]; bool any_ovf = false;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const uint64_t k0 = ((uint64_t)ka[r].y << 32) | ka[r].x, k1 = ((uint64_t)kb[r].y << 32) | kb[r].x;
@@ -423,6 +456,7 @@ __device__ __forceinline__ int map_both_strands_fast(const DevIndex& ix, const u
         else pending = more;
       }
     }
+  }
   }
   // one strand after the other (fewer masks live at once); a read maps to one strand at most, so the strand without hits
   // stops at its empty hit mask and never builds its extension masks. With `lds`, the colour descriptors of the strand that
@@ -618,15 +652,17 @@ __device__ __forceinline__ TriRec tri_load_record(const uint64_t* __restrict__ r
 // buckets, builds the masks, walks both strands and fills Strand<3> with w[r] / col[r] indexed by RESIDUE r.
 // (vmcnt retires in issue order: record loads issued BEFORE the bucket loads would make the bucket wait include the
 // HBM-cold record fetch; issued after, they overlap the mask/walk work.)
-struct TriProbe { uint64_t canon[3]; uint32_t meta[3]; uint4 ka[3], kb[3]; };   // (the bucket index is recomputed on the rare overflow path: 3 VGPRs less)
+template <bool CT> struct TriProbe { uint64_t canon[3]; uint32_t meta[3]; uint4 ka[3], kb[3]; };   // (the bucket index is recomputed on the rare overflow path: 3 VGPRs less)
+template <> struct TriProbe<true> { uint32_t want[3]; uint32_t meta[3]; uint4 ka[3], kb[3]; };      // compact table: ka = home bucket, kb = alternate bucket
 
-__device__ __forceinline__ void tri_issue(const DevIndex& ix, const TriRec& rec, int L, int lane, TriProbe& q) {
+template <bool CT>
+__device__ __forceinline__ void tri_issue(const DevIndex& ix, const TriRec& rec, int L, int lane, TriProbe<CT>& q) {
   const int K = ix.K, P = L - K + 1;
   const int i0 = 3 * lane;
   const uint64_t W = rec.W, NW = rec.NW; const uint32_t prevb0 = rec.prevb0; const bool prevok0 = rec.prevok0;
   const uint64_t kmask = (1ull << (2 * K)) - 1, nkmask = (1ull << K) - 1;
   const uint64_t RCW = rc_kmer(W & ((1ull << (2 * (K + 2))) - 1), K + 2);   // one reverse complement for the three k-mers
-  uint32_t bk[3];
+  uint32_t bk[3]; [[maybe_unused]] uint32_t bk2[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int i = i0 + r;
@@ -638,27 +674,44 @@ __device__ __forceinline__ void tri_issue(const DevIndex& ix, const TriRec& rec,
     const bool prev_ok = r ? !((NW >> (r - 1)) & 1) : prevok0;
     const uint64_t y = (RCW >> (2 * (2 - r))) & kmask;
     const uint64_t c = x < y ? x : y;
-    q.canon[r] = c;
+    if constexpr (CT) {
+      const CProbe pr = compact_probe(c, ix.chash);
+      q.want[r] = pr.want; bk[r] = validk ? pr.b1 : 0u; bk2[r] = validk ? pr.b2 : 0u;
+    } else {
+      q.canon[r] = c;
 #if defined(NB_ABLATE) && NB_ABLATE >= 3
-    bk[r] = validk ? (kmer_bucket(c, ix.hash) & 1023u) : 0u;   // timing-only build: every lookup lands in 32 KB of the table
+      bk[r] = validk ? (kmer_bucket(c, ix.hash) & 1023u) : 0u;   // timing-only build: every lookup lands in 32 KB of the table
 #else
-    bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;
+      bk[r] = validk ? kmer_bucket(c, ix.hash) : 0u;
 #endif
+    }
     q.meta[r] = (validk ? 1u : 0u) | ((x != c) ? 2u : 0u) | (next_ok ? 4u : 0u) | (nextb << 3) | (prev_ok ? 32u : 0u) | (prevb << 6);
   }
-  const Bucket* __restrict__ B = ix.buckets;
+  if constexpr (CT) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r) { const uint4* kp = reinterpret_cast<const uint4*>(&B[bk[r]]); q.ka[r] = kp[0]; q.kb[r] = kp[1]; }
+    for (int r = 0; r < 3; ++r) { q.ka[r] = load_cbucket(ix.ctable, bk[r]); q.kb[r] = load_cbucket(ix.ctable, bk2[r]); }
+  } else {
+    const Bucket* __restrict__ B = ix.buckets;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { const uint4* kp = reinterpret_cast<const uint4*>(&B[bk[r]]); q.ka[r] = kp[0]; q.kb[r] = kp[1]; }
+  }
 }
 
 // `lds` (or nullptr): this wave's six 64-lane rows of LDS. When given, the colour descriptors of the strand that has hits are
 // fetched straight into them (global_load_lds: no VGPR destination) as soon as the hit masks exist, so that their memory
 // round trip runs behind the scalar walk instead of after it. Returns which strand that was: 0 none, 1 read strand, 2 reverse.
-__device__ __forceinline__ int tri_finish(const DevIndex& ix, const TriProbe& q, int L, int lane, Strand<3>& F, Strand<3>& R, uint4 (*lds)[64] = nullptr) {
+template <bool CT>
+__device__ __forceinline__ int tri_finish(const DevIndex& ix, const TriProbe<CT>& q, int L, int lane, Strand<3>& F, Strand<3>& R, uint4 (*lds)[64] = nullptr) {
   const int K = ix.K;
+  const uint32_t* meta = q.meta; const uint4* ka = q.ka; const uint4* kb = q.kb;
+  uint32_t payF[3], payR[3];
+  if constexpr (CT) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) compact_match(ka[r], kb[r], q.want[r], (meta[r] >> 1) & 1u, meta[r] & 1u, payF[r], payR[r]);
+  } else {
   const Bucket* __restrict__ B = ix.buckets;
-  const uint64_t* canon = q.canon; const uint32_t* meta = q.meta; const uint4* ka = q.ka; const uint4* kb = q.kb;
-  uint32_t payF[3], payR[3]; bool ovf[3]; bool any_ovf = false;
+  const uint64_t* canon = q.canon;
+  bool ovf[3]; bool any_ovf = false;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const uint64_t k0 = ((uint64_t)ka[r].y << 32) | ka[r].x, k1 = ((uint64_t)kb[r].y << 32) | kb[r].x;
@@ -682,6 +735,7 @@ __device__ __forceinline__ int tri_finish(const DevIndex& ix, const TriProbe& q,
         else pending = more;
       }
     }
+  }
   }
   Tri HF, HR;
 #pragma unroll
@@ -815,7 +869,7 @@ __device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) 
 #ifndef NB_SE_WAVES_PER_EU
 #define NB_SE_WAVES_PER_EU 1, 6   // measured on MI355X (10M x 150bp, 1k seqs): 6 waves/SIMD 23.4 ms, 7 -> 28.1, 8 -> 25.5:
 #endif                             // the kernel is bound by L2-miss request rate, more waves only thrash L2
-template <int NR, int TW, bool TRI>
+template <int NR, int TW, bool TRI, bool CT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ctv, const DevClasses* __restrict__ ctp, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   constexpr bool LDS_DESC = TW == 1 && (TRI || NR == 2);   // (wide class rows go through `packed` anyway: a loss on c5; one round of positions: neutral)
@@ -856,15 +910,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
       Strand<NR> SF, SR;
       [[maybe_unused]] int pre = 0;                                          // strand whose descriptors wait in LDS (1 F, 2 R)
       if constexpr (TRI) {                                                  // 129..192 positions: three per lane
-        TriProbe q;
-        tri_issue(ix, rec, L, lane, q);
+        TriProbe<CT> q;
+        tri_issue<CT>(ix, rec, L, lane, q);
         prefetch_next();                              // this wave's next record, issued BEHIND the bucket loads
-        if constexpr (LDS_DESC) pre = tri_finish(ix, q, L, lane, SF, SR, s_desc[wave]);
-        else pre = tri_finish(ix, q, L, lane, SF, SR);
+        if constexpr (LDS_DESC) pre = tri_finish<CT>(ix, q, L, lane, SF, SR, s_desc[wave]);
+        else pre = tri_finish<CT>(ix, q, L, lane, SF, SR);
       } else {
         const uint64_t* __restrict__ rp = reads_ro + (size_t)r * a.stride;   // separate noalias kernel argument: lets the
-        if constexpr (LDS_DESC) pre = map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR, s_desc[wave]);   // compiler fetch the record
-        else map_both_strands_fast<NR>(ix, rp, a.nwb, L, lane, SF, SR);                                          // with scalar loads
+        if constexpr (LDS_DESC) pre = map_both_strands_fast<NR, CT>(ix, rp, a.nwb, L, lane, SF, SR, s_desc[wave]);   // compiler fetch the record
+        else map_both_strands_fast<NR, CT>(ix, rp, a.nwb, L, lane, SF, SR);                                          // with scalar loads
       }
       covF = SF.cov; covR = SR.cov;
       // candidates in preference order: larger coverage first, tie -> F   (SPEC §4 "Chosen orientation")
@@ -1008,7 +1062,7 @@ __device__ __forceinline__ int walk_general(const Mask<NR>& Hseed, const Mask<NR
 }
 
 // Map the sequence staged in `seq` (LDS). Returns coverage; S.V / S.col describe the visited positions.
-template <int NR>
+template <int NR, bool CT>
 __device__ __forceinline__ void map_staged(const DevIndex& ix, uint64_t* seq, int nwb, int L, int M, int lane, Strand<NR>& S) {
   const int K = ix.K, P = L - K + 1;
   Mask<NR> Hseed; int mm = 0;
@@ -1017,7 +1071,7 @@ __device__ __forceinline__ void map_staged(const DevIndex& ix, uint64_t* seq, in
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int i = lane + 64 * r;
-      const PosFacts f = position_facts(ix, seq, nwb, L, i, i < P);
+      const PosFacts f = position_facts<CT>(ix, seq, nwb, L, i, i < P);
       pay[r] = f.payF; S.col[r] = f.payF >> 10;
       H.w[r] = __ballot(f.hF); R.w[r] = __ballot(f.rF); LX.w[r] = __ballot(f.lF);
       RI.w[r] = __ballot(f.hF && ((f.payF >> 8) & 1u)); LI.w[r] = __ballot(f.hF && ((f.payF >> 9) & 1u));
@@ -1099,7 +1153,7 @@ __device__ __forceinline__ void combine_mates(bool paired, int reason1, int cov1
 // MODE 0: LDS-staged mapper (any num_mismatches, single-end or paired). MODE 1 / 2: exact mode (num_mismatches == 0) with
 // the hot kernel's front ends applied to each mate (1 = one position per lane, 2 = three positions per lane): no staging,
 // both strands of a mate from one pass of lookups — the path of paired FASTQ / paired BAM input.
-template <int NR, int TW, int MODE>
+template <int NR, int TW, int MODE, bool CT>
 __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevClasses ct, BatchArgs a) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   __shared__ uint64_t s_seq[4][GEN_WORDS];
@@ -1133,7 +1187,7 @@ __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevC
         const int nwb = second ? a.mnwb : a.nwb;
         stage_sequence(seq, src, nwb, L, (j & 1) != 0, lane);
         Strand<NR> S;
-        map_staged<NR>(ix, seq, nwb, L, a.num_mismatches, lane, S);
+        map_staged<NR, CT>(ix, seq, nwb, L, a.num_mismatches, lane, S);
         cov[j] = S.cov;
         rs[j] = evaluate_alignment<NR, TW>(ix, S, L, a, lane, eq[j]);
       }
@@ -1148,10 +1202,10 @@ __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevC
         Strand<NR> SF, SR;
         if constexpr (MODE == 2) {
           const TriRec rec = tri_load_record(src, nwb, L, ix.K, lane);
-          TriProbe q;
-          tri_issue(ix, rec, L, lane, q);
-          tri_finish(ix, q, L, lane, SF, SR);
-        } else map_both_strands_fast<NR>(ix, src, nwb, L, lane, SF, SR);
+          TriProbe<CT> q;
+          tri_issue<CT>(ix, rec, L, lane, q);
+          tri_finish<CT>(ix, q, L, lane, SF, SR);
+        } else map_both_strands_fast<NR, CT>(ix, src, nwb, L, lane, SF, SR);
         cov[2 * m] = SF.cov; cov[2 * m + 1] = SR.cov;
         rs[2 * m] = evaluate_alignment<NR, TW>(ix, SF, L, a, lane, eq[2 * m]);
         rs[2 * m + 1] = evaluate_alignment<NR, TW>(ix, SR, L, a, lane, eq[2 * m + 1]);
@@ -1206,7 +1260,7 @@ struct nb_ctx {
   int device = 0;
   int n_cu = 256;
   // bound index (device copies)
-  nb::Bucket* d_slots = nullptr; nb::ColDesc* d_desc = nullptr; uint64_t* d_packed = nullptr; nb::KmerHash hash{}; int W = 0, K = 0, n_seqs = 0; int64_t index_bytes = 0;
+  nb::Bucket* d_slots = nullptr; nb::CBucket* d_ctable = nullptr; bool compact = false; nb::CHash chash{}; nb::ColDesc* d_desc = nullptr; uint64_t* d_packed = nullptr; nb::KmerHash hash{}; int W = 0, K = 0, n_seqs = 0; int64_t index_bytes = 0;
   // class table
   nb::DevClasses ct{}; nb::DevClasses* d_ct = nullptr; int64_t max_classes = 0;   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
   // score_percent table
@@ -1246,13 +1300,13 @@ static int resident_blocks(nb_ctx* c, K kernel, long long n_templates) {
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
-template <int NR, int TW, bool TRI>
+template <int NR, int TW, bool TRI, bool CT>
 static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
   static thread_local int cached_blocks = 0; static thread_local int cached_cu = 0;
-  if (!cached_blocks || cached_cu != c->n_cu || std::getenv("NB_BLOCKS_PER_CU")) { cached_blocks = resident_blocks(c, nb_align_se_kernel<NR, TW, TRI>, 1ll << 40); cached_cu = c->n_cu; }
+  if (!cached_blocks || cached_cu != c->n_cu || std::getenv("NB_BLOCKS_PER_CU")) { cached_blocks = resident_blocks(c, nb_align_se_kernel<NR, TW, TRI, CT>, 1ll << 40); cached_cu = c->n_cu; }
   long long blocks = cached_blocks; const long long need = (a.n + 3) / 4;
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW, TRI>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, (const DevClasses*)c->d_ct, a, a.reads);
+  hipLaunchKernelGGL((nb_align_se_kernel<NR, TW, TRI, CT>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, (const DevClasses*)c->d_ct, a, a.reads);
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
@@ -1260,42 +1314,42 @@ static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStrea
 // three-positions-per-lane front end: 129..192 positions and k <= 29 (window of k+3 bases in one 64-bit word)
 static bool use_tri(int positions, int k) { return positions > 128 && positions <= 192 && k <= 29; }
 
-template <int NR, int TW, int MODE>
+template <int NR, int TW, int MODE, bool CT>
 static int launch_general(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
-  const long long blocks = resident_blocks(c, nb_align_general_kernel<NR, TW, MODE>, a.n);
-  hipLaunchKernelGGL((nb_align_general_kernel<NR, TW, MODE>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
+  const long long blocks = resident_blocks(c, nb_align_general_kernel<NR, TW, MODE, CT>, a.n);
+  hipLaunchKernelGGL((nb_align_general_kernel<NR, TW, MODE, CT>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
 
-template <int TW>
+template <int TW, bool CT>
 static int dispatch_general(nb_ctx* c, int nr, int positions, bool exact, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
-  if (exact && use_tri(positions, ix.K)) return launch_general<3, TW, 2>(c, ix, a, s);
+  if (exact && use_tri(positions, ix.K)) return launch_general<3, TW, 2, CT>(c, ix, a, s);
   if (exact) switch (nr) {
-    case 1: return launch_general<1, TW, 1>(c, ix, a, s);
-    case 2: return launch_general<2, TW, 1>(c, ix, a, s);
-    case 3: return launch_general<3, TW, 1>(c, ix, a, s);
-    case 4: return launch_general<4, TW, 1>(c, ix, a, s);
-    default: return launch_general<5, TW, 1>(c, ix, a, s);
+    case 1: return launch_general<1, TW, 1, CT>(c, ix, a, s);
+    case 2: return launch_general<2, TW, 1, CT>(c, ix, a, s);
+    case 3: return launch_general<3, TW, 1, CT>(c, ix, a, s);
+    case 4: return launch_general<4, TW, 1, CT>(c, ix, a, s);
+    default: return launch_general<5, TW, 1, CT>(c, ix, a, s);
   }
   switch (nr) {
-    case 1: return launch_general<1, TW, 0>(c, ix, a, s);
-    case 2: return launch_general<2, TW, 0>(c, ix, a, s);
-    case 3: return launch_general<3, TW, 0>(c, ix, a, s);
-    case 4: return launch_general<4, TW, 0>(c, ix, a, s);
-    default: return launch_general<5, TW, 0>(c, ix, a, s);
+    case 1: return launch_general<1, TW, 0, CT>(c, ix, a, s);
+    case 2: return launch_general<2, TW, 0, CT>(c, ix, a, s);
+    case 3: return launch_general<3, TW, 0, CT>(c, ix, a, s);
+    case 4: return launch_general<4, TW, 0, CT>(c, ix, a, s);
+    default: return launch_general<5, TW, 0, CT>(c, ix, a, s);
   }
 }
 
-template <int TW>
+template <int TW, bool CT>
 static int dispatch_se(nb_ctx* c, int nr, int positions, const DevIndex& ix, const BatchArgs& a, hipStream_t s) {
-  if (use_tri(positions, ix.K)) return launch_se<3, TW, true>(c, ix, a, s);
+  if (use_tri(positions, ix.K)) return launch_se<3, TW, true, CT>(c, ix, a, s);
   switch (nr) {
-    case 1: return launch_se<1, TW, false>(c, ix, a, s);
-    case 2: return launch_se<2, TW, false>(c, ix, a, s);
-    case 3: return launch_se<3, TW, false>(c, ix, a, s);
-    case 4: return launch_se<4, TW, false>(c, ix, a, s);
-    default: return launch_se<5, TW, false>(c, ix, a, s);
+    case 1: return launch_se<1, TW, false, CT>(c, ix, a, s);
+    case 2: return launch_se<2, TW, false, CT>(c, ix, a, s);
+    case 3: return launch_se<3, TW, false, CT>(c, ix, a, s);
+    case 4: return launch_se<4, TW, false, CT>(c, ix, a, s);
+    default: return launch_se<5, TW, false, CT>(c, ix, a, s);
   }
 }
 
@@ -1329,7 +1383,7 @@ int32_t nb_ctx_create(int32_t device_id, int64_t max_classes, nb_ctx** out) {
 int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
-  (void)hipFree(c->d_slots); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
+  (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
   (void)hipFree(c->ct.counts); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
@@ -1351,9 +1405,10 @@ int32_t nb_index_destroy(nb_index* ix) { if (ix) { delete ix->h; delete ix; } re
 int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
   if (!ix || !s) { set_error("nb_index_stats: null argument"); return NB_ERR_INVALID; }
   const HostIndex& h = *ix->h;
-  s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
+  s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = h.compact ? (int64_t)h.ctable.size() * 2 : (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
   s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
-  s->device_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
+  s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0;
+  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
   return NB_OK;
 }
 
@@ -1365,6 +1420,16 @@ int32_t nb_index_query(const nb_index* ix, const char* kmer, uint8_t* lext, uint
     x |= (uint64_t)c << (2 * j);
   }
   const uint64_t y = rc_kmer_host(x, h.k), canon = x < y ? x : y; const int o = (x != canon);
+  if (h.compact) {
+    const CProbe pr = compact_probe(canon, h.chash);
+    const uint32_t wantk[2] = {pr.want | (uint32_t)o, pr.want | (uint32_t)o | 2u}; const uint32_t bs[2] = {pr.b1, pr.b2};
+    for (int t = 0; t < 2; ++t) for (int j = 0; j < 2; ++j) { const CEntry& e = h.ctable[bs[t]].e[j];
+        if (e.key == wantk[t] && e.pay != PAY_ABSENT) { const uint32_t p = e.pay;
+          if (rext) *rext = p & 15; if (lext) *lext = (p >> 4) & 15; if (r_int) *r_int = (p >> 8) & 1; if (l_int) *l_int = (p >> 9) & 1;
+          if (bits) std::memcpy(bits, h.eq_rows.data() + (size_t)(p >> 10) * h.words, (size_t)h.words * 8);
+          return 1; } }
+    return 0;
+  }
   uint32_t b = kmer_bucket(canon, h.hash);
   for (;;) {
     const Bucket& bk = h.buckets[b];
@@ -1383,19 +1448,24 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   if (!c || !ix) { set_error("nb_index_upload: null argument"); return NB_ERR_INVALID; }
   NB_HIP(hipSetDevice(c->device));
   HostIndex& h = *ix->h;
-  (void)hipFree(c->d_slots); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.rows);
-  c->d_slots = nullptr; c->d_desc = nullptr; c->d_packed = nullptr; c->ct.rows = nullptr;
+  (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.rows);
+  c->d_slots = nullptr; c->d_ctable = nullptr; c->d_desc = nullptr; c->d_packed = nullptr; c->ct.rows = nullptr;
+  c->compact = h.compact; c->chash = h.chash;
+  if (h.compact) {
+    NB_HIP(hipMalloc((void**)&c->d_ctable, h.ctable.size() * sizeof(CBucket)));
+    NB_HIP(hipMemcpy(c->d_ctable, h.ctable.data(), h.ctable.size() * sizeof(CBucket), hipMemcpyHostToDevice));
+  } else
   NB_HIP(hipMalloc((void**)&c->d_slots, h.buckets.size() * sizeof(Bucket)));
   NB_HIP(hipMalloc((void**)&c->d_desc, h.desc.size() * sizeof(ColDesc)));
   NB_HIP(hipMalloc((void**)&c->d_packed, h.packed.size() * 8));
-  NB_HIP(hipMemcpy(c->d_slots, h.buckets.data(), h.buckets.size() * sizeof(Bucket), hipMemcpyHostToDevice));
+  if (!h.compact) NB_HIP(hipMemcpy(c->d_slots, h.buckets.data(), h.buckets.size() * sizeof(Bucket), hipMemcpyHostToDevice));
   NB_HIP(hipMemcpy(c->d_desc, h.desc.data(), h.desc.size() * sizeof(ColDesc), hipMemcpyHostToDevice));
   NB_HIP(hipMemcpy(c->d_packed, h.packed.data(), h.packed.size() * 8, hipMemcpyHostToDevice));
   NB_HIP(hipMalloc((void**)&c->ct.rows, (size_t)c->max_classes * (size_t)h.words * 8));
   if (!c->d_ct) NB_HIP(hipMalloc((void**)&c->d_ct, sizeof(DevClasses)));
   NB_HIP(hipMemcpy(c->d_ct, &c->ct, sizeof(DevClasses), hipMemcpyHostToDevice));
   c->hash = h.hash; c->W = h.words; c->K = h.k; c->n_seqs = h.n_seqs;
-  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); h.uploaded = 1;
+  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
 }
 
@@ -1424,7 +1494,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
                        const uint64_t* d_mates, const uint16_t* d_mate_lens, int32_t mate_max_len, int64_t n,
                        uint32_t* d_out_class, uint32_t* d_out_info, uint64_t* d_out_cov, void* stream) {
   if (!c || !cfg || !d_reads || n < 0 || max_len < 1) { set_error("nb_align_batch: bad arguments"); return NB_ERR_INVALID; }
-  if (!c->d_slots) { set_error("nb_align_batch: no index uploaded to this ctx"); return NB_ERR_INVALID; }
+  if (!c->d_slots && !c->d_ctable) { set_error("nb_align_batch: no index uploaded to this ctx"); return NB_ERR_INVALID; }
   if (cfg->k != c->K) { set_error("nb_align_batch: cfg.k differs from the uploaded index's k"); return NB_ERR_INVALID; }
   if (cfg->strand_filter < 0 || cfg->strand_filter > 3 || cfg->intersect_level < 0 || cfg->intersect_level > 2) { set_error("nb_align_batch: bad strand_filter/intersect_level"); return NB_ERR_INVALID; }
   if (cfg->num_mismatches < 0 || cfg->num_mismatches > 64) { set_error("nb_align_batch: num_mismatches must be in 0..64"); return NB_ERR_INVALID; }
@@ -1438,7 +1508,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   NB_HIP(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
   int rc = ensure_pct_table(c, cfg->score_percent, lmax, s); if (rc != NB_OK) return rc;
-  DevIndex ix{c->d_slots, c->d_desc, c->d_packed, c->hash, c->W, c->K};
+  DevIndex ix{c->d_slots, c->d_ctable, c->d_desc, c->d_packed, c->hash, c->chash, c->W, c->K};
   BatchArgs a{};
   a.reads = d_reads; a.lens = d_lens; a.max_len = max_len; a.stride = (int)nb_packed_stride_words(max_len); a.nwb = (max_len + 31) / 32;
   a.mates = d_mates; a.mate_lens = d_mate_lens; a.mate_max_len = mate_max_len;
@@ -1449,9 +1519,13 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   a.require_valid_pair = cfg->require_valid_pair; a.strand_filter = cfg->strand_filter;
   const int nr = positions < 1 ? 1 : (positions + 63) / 64;
   if (d_mates || cfg->num_mismatches > 0)   // pairs and tolerated mismatches take the general (eager, LDS-staged) kernel
-    return (c->W <= 64) ? dispatch_general<1>(c, nr, positions, cfg->num_mismatches == 0, ix, a, s)
-                        : dispatch_general<4>(c, nr, positions, cfg->num_mismatches == 0, ix, a, s);
-  return (c->W <= 64) ? dispatch_se<1>(c, nr, positions, ix, a, s) : dispatch_se<4>(c, nr, positions, ix, a, s);
+  {
+    const bool exact = cfg->num_mismatches == 0;
+    if (c->compact) return (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, exact, ix, a, s) : dispatch_general<4, true>(c, nr, positions, exact, ix, a, s);
+    return (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, exact, ix, a, s) : dispatch_general<4, false>(c, nr, positions, exact, ix, a, s);
+  }
+  if (c->compact) return (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, a, s) : dispatch_se<4, true>(c, nr, positions, ix, a, s);
+  return (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, a, s) : dispatch_se<4, false>(c, nr, positions, ix, a, s);
 }
 
 int32_t nb_classes_count(nb_ctx* c, int64_t* n) {
@@ -1557,8 +1631,9 @@ int32_t nb_copy_d2h_async(nb_ctx* c, void* dst, const void* d_src, int64_t bytes
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired) {
   static thread_local char buf[96];
   const int positions = max_len - k + 1; const int nr = positions < 1 ? 1 : (positions + 63) / 64; const int W = (n_seqs + 63) / 64;
-  if (paired) std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d, %d>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? 2 : 1);
-  else std::snprintf(buf, sizeof buf, "nb_align_se_kernel<%d, %d, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? "true" : "false");
+  const char* ct = (k <= COMPACT_MAX_K && !(std::getenv("NB_TABLE") && std::string(std::getenv("NB_TABLE")) == "wide")) ? "true" : "false";   // compact table (nb_internal.h)
+  if (paired) std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d, %d, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? 2 : 1, ct);
+  else std::snprintf(buf, sizeof buf, "nb_align_se_kernel<%d, %d, %s, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? "true" : "false", ct);
   return buf;
 }
 

@@ -112,8 +112,9 @@ def synth_reads_packed_torch(seqs, n, read_len, seed, device, chunk=1 << 20, fra
         reads = torch.where(rnd[:, None], torch.randint(0, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8), reads)
         isn = torch.rand((m, read_len), generator=g, device=device) < n_rate
         reads = torch.where(isn, torch.full_like(reads, 4), reads)
-        if lo == 0 and return_codes_of_first:
-            first_codes = reads[:return_codes_of_first].cpu().numpy()
+        if lo < return_codes_of_first:                 # codes of the first reads, across chunks
+            part = reads[:return_codes_of_first - lo].cpu().numpy()
+            first_codes = part if first_codes is None else np.concatenate([first_codes, part])
         two = torch.where(isn, torch.zeros_like(reads), reads).to(torch.int64)
         pad = torch.zeros((m, nwb * 32), dtype=torch.int64, device=device)
         pad[:, :read_len] = two

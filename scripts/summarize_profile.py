@@ -34,7 +34,7 @@ def main(out, cfg="c2"):
         print(",".join(cols))
         for r in rows[:12]:
             print(",".join(str(r.get(c, ""))[:110] for c in cols))
-    for tag in ("pmc_fetch", "pmc_write", "pmc_l2"):
+    for tag in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_l1"):
         for f in find(os.path.join(out, tag), "*counter_collection.csv"):
             print(f"\n## {tag} ({os.path.relpath(f, out)}) — per-dispatch counter values of the alignment kernel")
             agg = {}

@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests: run the HIP path through the C-ABI and the oracle on the same inputs."""
+import os
+
 import numpy as np
 
 from nimble_amd import engine, synth
@@ -98,3 +100,89 @@ def write_bam(path, records, refs=(("chr1", 1000),), block=3000):
         for i in range(0, len(raw), block):
             f.write(_bgzf_block(raw[i:i + block]))
         f.write(_bgzf_block(b""))
+
+
+# ---- size-independent properties for batches too large for the oracle (tests/test_fullsize_properties_gpu.py, tests/test_c3_gpu.py) ----
+def _revcomp_packed(d_reads, L):
+    """Reverse-complement packed reads on the GPU with torch ops (independent of the kernels under test)."""
+    import torch
+    n = d_reads.shape[0]
+    nwb, nwn = (L + 31) // 32, (L + 63) // 64
+    dev = d_reads.device
+    sh2 = (torch.arange(32, dtype=torch.int64, device=dev) * 2)[None, None, :]
+    sh1 = torch.arange(64, dtype=torch.int64, device=dev)[None, None, :]
+    out = torch.empty_like(d_reads)
+    for lo in range(0, n, 1 << 20):
+        w = d_reads[lo:lo + (1 << 20)]
+        m = w.shape[0]
+        bases = ((w[:, :nwb, None] >> sh2) & 3).reshape(m, nwb * 32)[:, :L]
+        isn = ((w[:, nwb:, None] >> sh1) & 1).reshape(m, nwn * 64)[:, :L]
+        rb = torch.where(isn.flip(1) == 1, torch.zeros_like(bases), 3 - bases.flip(1))
+        pad = torch.zeros((m, nwb * 32), dtype=torch.int64, device=dev); pad[:, :L] = rb
+        out[lo:lo + m, :nwb] = (pad.view(m, nwb, 32) << sh2).sum(dim=2)
+        npad = torch.zeros((m, nwn * 64), dtype=torch.int64, device=dev); npad[:, :L] = isn.flip(1)
+        out[lo:lo + m, nwb:] = (npad.view(m, nwn, 64) << sh1).sum(dim=2)
+    return out
+
+
+def _run(index, cfg, d_reads, L, max_classes):
+    import torch
+    n = d_reads.shape[0]
+    ctx = engine.Context(0, max_classes=max_classes)
+    ctx.upload(index)
+    oc = torch.empty(n, dtype=torch.int32, device=d_reads.device)
+    oi = torch.empty(n, dtype=torch.int32, device=d_reads.device)
+    ctx.align_batch(cfg, d_reads, None, L, oc, oi, None, n=n)
+    ctx.sync()
+    rows, counts = ctx.classes()
+    res = dict(cls=oc, info=oi, rows=rows, counts=counts, reasons=ctx.reasons())
+    ctx.close()
+    return res
+
+
+def _multiset(rows, counts):
+    return {r.tobytes(): int(c) for r, c in zip(rows, counts) if c}
+
+
+
+
+def check_fullsize_properties(index, strs, cfg, d_reads, first_codes, L, max_classes=1 << 21):
+    """conservation, an oracle-checked sample (first_codes = codes of the first reads of d_reads), idempotence, linearity over a
+    split, strand symmetry. Returns dict(called_frac, sample_sets)."""
+    from oracle import oracle
+    n = d_reads.shape[0]
+    a = _run(index, cfg, d_reads, L, max_classes)
+    info = a["info"].cpu().numpy().view(np.uint32)
+    reason = (info >> 16) & 0xFF
+    # conservation
+    assert int(a["reasons"].sum()) == n and int(a["counts"].sum()) == int((reason == 0).sum()) == int(a["reasons"][0])
+    assert (np.bincount(reason, minlength=12) == a["reasons"]).all()
+    # oracle-checked sample
+    ns = first_codes.shape[0]
+    blob, off = synth.reads_to_ascii(first_codes)
+    ora = oracle.OracleIndex(strs, index.k).align(cfg, blob, off, n_threads=min(16, os.cpu_count() or 1))
+    cls = a["cls"][:ns].cpu().numpy().view(np.uint32)
+    sets = np.zeros((ns, index.words), dtype=np.uint64)
+    called = cls != engine.NO_CLASS
+    sets[called] = a["rows"][cls[called]]
+    assert (sets == ora["set_bits"]).all() and ((info[:ns] & 0xFFFF) == ora["score"]).all() and (reason[:ns] == ora["reason"]).all()
+    assert (((info[:ns] >> 24) & 1) == ora["orientation"]).all()
+    # idempotence
+    b = _run(index, cfg, d_reads, L, max_classes)
+    assert bool((b["info"] == a["info"]).all()) and _multiset(b["rows"], b["counts"]) == _multiset(a["rows"], a["counts"])
+    del b
+    # linearity over a split
+    h1, h2 = _run(index, cfg, d_reads[: n // 2], L, max_classes), _run(index, cfg, d_reads[n // 2:], L, max_classes)
+    merged = _multiset(h1["rows"], h1["counts"])
+    for k, v in _multiset(h2["rows"], h2["counts"]).items():
+        merged[k] = merged.get(k, 0) + v
+    assert merged == _multiset(a["rows"], a["counts"])
+    del h1, h2
+    # strand symmetry
+    rc = _run(index, cfg, _revcomp_packed(d_reads, L), L, max_classes)
+    assert _multiset(rc["rows"], rc["counts"]) == _multiset(a["rows"], a["counts"])
+    info_rc = rc["info"].cpu().numpy().view(np.uint32)
+    assert ((info_rc & 0xFFFF) == (info & 0xFFFF)).all() and (((info_rc >> 16) & 0xFF) == reason).all()
+    flipped = ((info_rc >> 24) & 1) != ((info >> 24) & 1)
+    assert flipped[reason == 0].mean() > 0.999          # ties between strands (both orientations equal) are the only exceptions
+    return {"called_frac": float(a["reasons"][0]) / n, "sample_sets": sets}

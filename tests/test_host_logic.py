@@ -474,3 +474,29 @@ def test_fused_merge_rows_wide_ids():
     f, s = torch.from_numpy(rng.integers(0, 5, n)), torch.from_numpy(rng.integers(1, 3, n))
     out = fused._merge_wide(cb, umi, f, s)
     assert {k[:3]: k[3] for k in zip(*[x.tolist() for x in out])} == ref(cb, umi, f, s)
+
+
+def test_bench_reference_binary_hook(tmp_path, monkeypatch, built):
+    """bench.py times a nimble-aligner binary ONLY when NIMBLE_ALIGNER_BIN names one, with the argv the reference
+    builds (/root/reference/nimble/__main__.py:177-189). A stand-in script records its argv; nothing is ever downloaded."""
+    import importlib.util
+    import stat
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    _, seqs, _ = synth.synth_library(2, 3, locus_len=300, seed=5)
+    strs = [synth.codes_to_str(s) for s in seqs]
+    codes = synth.synth_reads(seqs, 50, 100, seed=1)
+    assert bench.time_reference_binary(None, codes, strs, 4) is None
+    assert bench.time_reference_binary(str(tmp_path / "missing"), codes, strs, 4) is None
+    fake = tmp_path / "aligner"
+    fake.write_text(f"#!/bin/sh\necho \"$@\" > {tmp_path}/argv.txt\nwc -l < \"$2\" > {tmp_path}/lines.txt\nexit 0\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+    r = bench.time_reference_binary(str(fake), codes, strs, 4)
+    assert r["kind"] == "reference" and r["cores"] == 4 and r["value"] > 0
+    argv = open(tmp_path / "argv.txt").read().split()
+    assert argv[0] == "--input" and argv[1].endswith("reads.fastq") and argv[2:6] == ["-c", "4", "--strand_filter", "unstranded"]
+    assert argv[6] == "-r" and argv[7].endswith("lib.json") and argv[8] == "-o" and argv[9].endswith("out.tsv")
+    assert int(open(tmp_path / "lines.txt").read()) == 200            # 50 records x 4 lines
+    fake.write_text("#!/bin/sh\nexit 3\n")
+    assert bench.time_reference_binary(str(fake), codes, strs, 4) is None
