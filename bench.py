@@ -63,6 +63,27 @@ def cpu_baseline(oix, cfg, codes, strs, args, t_oidx):
                       f"alignment only, oracle index build {t_oidx:.1f} s not counted); C++ restatement of docs/SPEC.md, not the Rust nimble-aligner"}
 
 
+def secondary_roofline(l2_requests, miss_requests, table_mb, kernel_s, n_reads):
+    """Gather-rate ceiling from the committed microbenchmark (16-byte random requests, best over the occupancies measured): the row of
+    the smallest table at least as large as this index's k-mer table. None without a PMC pass of this workload."""
+    path = os.path.join(ROOT, "profiles", "r02_gather_microbench.jsonl")
+    if not os.path.exists(path) or not (l2_requests or miss_requests):
+        return None
+    rows = [json.loads(l) for l in open(path) if l.strip()]
+    sizes = sorted({r["table_MB"] for r in rows})
+    size = next((s for s in sizes if s >= table_mb), sizes[-1])
+    peak = max(r["G_requests_per_s"] for r in rows if r["table_MB"] == size and r["req_bytes"] == 16)
+    if l2_requests:
+        ach = l2_requests / kernel_s / 1e9
+        return {"bound": "l1_to_l2_gather_requests", "achieved": ach, "peak": peak, "unit": "G requests/s", "frac": ach / peak,
+                "requests_per_read": l2_requests / n_reads, "l2_misses_per_read": (miss_requests / n_reads) if miss_requests else None,
+                "peak_source": f"scripts/gather_bench.hip, random 16-B requests from a {size:g} MB table (profiles/r02_gather_microbench.jsonl)"}
+    fabric = max(r["G_requests_per_s"] for r in rows if r["table_MB"] == sizes[-2 if len(sizes) > 1 else -1] and r["req_bytes"] == 32)
+    ach = miss_requests / kernel_s / 1e9
+    return {"bound": "l2_miss_requests", "achieved": ach, "peak": fabric, "unit": "G requests/s", "frac": ach / fabric, "misses_per_read": miss_requests / n_reads,
+            "peak_source": "scripts/gather_bench.hip, random 32-B requests from a table beyond L2 (profiles/r02_gather_microbench.jsonl)"}
+
+
 def time_reference_binary(path, codes, strs, cores, max_reads=2_000_000):
     """if a nimble-aligner binary is supplied through NIMBLE_ALIGNER_BIN, time it on a sample of the same batch with
     the reference's argv: [bin, "--input", fastq, "-c", N, "--strand_filter", "unstranded", "-r", lib.json, "-o", out]
@@ -240,7 +261,7 @@ def main():
 
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
     # from the committed rocprofv3 PMC passes of the SAME workload (scripts/profile_gpu.sh -> profiles/*_traffic.json).
-    traffic, traffic_src, miss_requests, sq = None, None, None, None
+    traffic, traffic_src, miss_requests, l2_requests, sq = None, None, None, None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
@@ -250,6 +271,7 @@ def main():
         if (t.get("reads_per_gpu"), t.get("read_len"), t.get("n_seqs"), t.get("k")) == (n, L, len(strs), args.k) and "traffic_bytes_per_launch" in t:
             traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.basename(f)
             miss_requests = t.get("TCC_MISS_sum")
+            l2_requests = t.get("TCP_TCC_READ_REQ_sum")
             sq = t.get("sq_per_read")
 
     # ---- optional: per-cell counts for the 10x workload (BASELINE configs[2] asks for them), outside the timed region ----
@@ -307,15 +329,16 @@ def main():
         "config": {"workload": f"{n} x {L}bp single-end reads per GPU vs {len(strs)}-seq HLA-like library; BASELINE {preset['what']}; k={args.k}",
                    "reads_per_gpu": n, "read_len": L, "n_seqs": len(strs), "k": args.k, "parallelism": f"reads sharded x{world}, index replicated"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                     "traffic_note": (f"bytes per launch, (FETCH_SIZE + WRITE_SIZE) KB from {traffic_src}: L2<->fabric requests, mostly served by the "
-                                      "Infinity Cache; algorithmic bytes per launch = " + str(bytes_per_read * n)) if traffic else None,
+                     "traffic_note": (f"bytes per launch, (FETCH_SIZE + WRITE_SIZE) KB from {traffic_src}: L2<->fabric requests (64 B per L2 miss; for scattered "
+                                      "16..64-B gathers FETCH_SIZE was calibrated against a known request count, profiles/r02_fetch_calibration.txt: it counts "
+                                      "64 B per missing request, no x2 correction applies); algorithmic bytes per launch = " + str(bytes_per_read * n)) if traffic else None,
                      "kernel": engine._lib.lib().nb_kernel_name(L, args.k, len(strs), 0).decode(), "kernel_ms_avg": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_read": bytes_per_read},
-        # The nearest hard memory-side ceiling (profiles/r01_tuning_notes.md; the binding constraint is instruction issue): the rate at which L2-miss requests
-        # (64 B each, TCC_MISS_sum of the committed PMC pass) can be served by the fabric / Infinity Cache / HBM, measured
-        # at 55-57 G requests/s on this chip (two-choice cuckoo experiment on c2; c5, whose index lives in HBM, sits there).
-        "secondary_roofline": ({"bound": "l2_miss_requests", "achieved": miss_requests / avg_kernel_s / 1e9, "peak": 56.0, "unit": "G requests/s",
-                                "frac": miss_requests / avg_kernel_s / 1e9 / 56.0, "misses_per_read": miss_requests / n} if miss_requests else None),
+        # The nearest memory-side ceiling: the rate at which the chip serves RANDOM 16-byte gathers (one cuckoo bucket = one dwordx4 = one
+        # L1->L2 request) from a table of this size, MEASURED by the standalone microbenchmark scripts/gather_bench.hip
+        # (profiles/r02_gather_microbench.jsonl: 264 G requests/s from a 3 MB L2-resident table, 61 G from 49 MB in the Infinity Cache,
+        # 55 G from 446 MB in HBM). achieved = L1->L2 read requests of the kernel (TCP_TCC_READ_REQ_sum of the committed PMC pass) / time.
+        "secondary_roofline": secondary_roofline(l2_requests, miss_requests, stats["table_bytes"] / 1e6, avg_kernel_s, n),
         # what binds the kernel (profiles/r01_tuning_notes.md): instruction issue. Instructions issued per read (SQ counters of the
         # committed PMC pass) against the issue slots a SIMD has per read at this occupancy: above 1.0 = ports saturated.
         "issue": ({"instructions_per_read": sq["SQ_ACTIVE_INST_ANY"], "valu": sq["SQ_INSTS_VALU"], "salu": sq["SQ_INSTS_SALU"], "vmem": sq["SQ_INSTS_VMEM"],
@@ -326,7 +349,7 @@ def main():
         # identical to the oracle on a sample of this very batch: self-consistency of the two implementations of docs/SPEC.md (HIP vs
         # C++ restatement), NOT parity with the Rust nimble-aligner, which stays unpinned (no binary, source or vectors offline)
         "oracle_self_consistency_ok": parity,
-        "index": {"kmers": stats["n_kmers"], "colours": stats["n_colours"], "table_MB": stats["table_slots"] * 16 / 1e6,
+        "index": {"kmers": stats["n_kmers"], "colours": stats["n_colours"], "table_MB": stats["table_bytes"] / 1e6, "compact_table": bool(stats["compact"]),
                   "device_MB": stats["device_bytes"] / 1e6, "build_s": t_index},
         "per_cell": per_cell,
         "classes": int(glob_rows.shape[0]), "called_frac": float(reasons[0] / max(1, reasons.sum())), "readgen_s": t_gen,
