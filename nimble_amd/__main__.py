@@ -4,6 +4,7 @@ Flag surface copied from /root/reference/nimble/__main__.py:389-431 (generate :3
 :403-418, fastq-to-bam :424-431). `download` and `plot` exist in the reference but are outside the hot path (network
 fetch of the Rust binary, HTML plotting): they are accepted and answered with an explanatory error."""
 import argparse
+import os
 import sys
 
 from .align import TenxOptions, align
@@ -35,6 +36,8 @@ def build_parser():
     a.add_argument("--cb-length", help="Length of cell barcode (default: 16).", type=int, default=16)
     a.add_argument("--umi-length", help="Length of UMI (default: 12).", type=int, default=12)
     a.add_argument("--device", help="GPU index (default 0).", type=int, default=0)
+    a.add_argument("--devices", help="Comma-separated GPU indices: one process per GPU (reads sharded, index replicated; counts reduced over RCCL, "
+                                     "outputs identical to a single-GPU run). Under torchrun the ranks are taken from the environment instead.", type=str, default=None)
     a.add_argument("--report-output", help="Also write the per-cell counts `report` would produce from the per-read table (barcoded input only).", type=str, default=None)
     a.add_argument("--report-threshold", help="Threshold of the fused report (default: 0.05).", type=float, default=0.05)
     a.add_argument("--report-disable-thresholding", help="Disable thresholding in the fused report.", action="store_true", default=False)
@@ -60,6 +63,36 @@ def build_parser():
     return parser
 
 
+def _spawn_ranks(argv, devices):
+    """`align --devices 0,1,...`: one child process per GPU, started BEFORE anything in this process touches a GPU; each child is the
+    same command line with its rank in the environment (RANK / WORLD_SIZE / LOCAL_RANK / NB_DEVICES, rendezvous on 127.0.0.1). Returns
+    the largest exit code (the reference's only status channel, __main__.py:198,211)."""
+    import socket
+    import subprocess
+    if len(devices) < 1:
+        print("Error -- --devices needs at least one GPU index", file=sys.stderr)
+        return 1
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out, skip = [], False
+    for a in argv:                              # the children get the command line without --devices
+        if skip:
+            skip = False
+        elif a == "--devices":
+            skip = True
+        elif not a.startswith("--devices="):
+            out.append(a)
+    procs = []
+    for r in range(len(devices)):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(r), NB_DEVICES=",".join(map(str, devices)),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if len(set(devices)) < len(devices):    # ranks sharing a GPU (rehearsal on a one-GPU box): RCCL needs one device per rank
+            env.setdefault("NB_DIST_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, "-m", "nimble_amd"] + out, env=env))
+    return max(p.wait() for p in procs)
+
+
 def main(argv=None):
     parser = build_parser()
     args, extra = parser.parse_known_args(argv)
@@ -72,6 +105,8 @@ def main(argv=None):
     if args.subcommand == "generate":
         generate(args.file, args.opt_file, args.output_path)
         return 0
+    if args.subcommand == "align" and args.devices and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return _spawn_ranks(list(sys.argv[1:] if argv is None else argv), [int(x) for x in args.devices.split(",") if x != ""])
     if args.subcommand == "align":
         tenx = TenxOptions(args.map, args.cb_length, args.umi_length) if args.tenx else None
         return align(args.reference, args.output, args.input, args.num_cores, args.strand_filter, args.trim, args.tmpdir,

@@ -151,7 +151,10 @@ class BamReader:
 class LibraryRun:
     """One reference library on one GPU: index, context, class -> feature-string cache, output writer."""
 
-    def __init__(self, lib, out_path, strand_filter, device_id, per_read):
+    def __init__(self, lib, out_path, strand_filter, device_id, per_read, world=1, rank=0, ctx=None):
+        """`ctx` (tests of the multi-rank merge layer): an object with the class-table interface of engine.Context (n_classes,
+        class_rows, classes, reasons) standing in for the GPU context; by default the index is built and uploaded to `device_id`."""
+        self.world, self.rank = world, rank
         self.lib = lib if isinstance(lib, Library) else Library(lib)
         c = self.lib.config
         self.cfg = engine.make_config(k=self.lib.k, score_threshold=c["score_threshold"], score_filter=c["score_filter"],
@@ -160,9 +163,12 @@ class LibraryRun:
                                       require_valid_pair=c["require_valid_pair"], strand_filter=strand_filter)
         self.max_hits = int(c["max_hits_to_report"])
         self.multi_hits = int(c["discard_multi_hits"])
-        self.index = engine.Index(self.lib.sequences, self.lib.k)
-        self.ctx = engine.Context(device_id, max_classes=1 << 22)
-        self.ctx.upload(self.index)
+        if ctx is None:
+            self.index = engine.Index(self.lib.sequences, self.lib.k)
+            self.ctx = engine.Context(device_id, max_classes=1 << 22)
+            self.ctx.upload(self.index)
+        else:
+            self.index, self.ctx = None, ctx
         self.out_path = out_path
         self.per_read = per_read
         self._feature_names = sorted(set(self.lib.features))
@@ -183,16 +189,29 @@ class LibraryRun:
         self._row_buf = None
         self._gz_buf = None
         self.gz_threads = 1
+        self.part_index = []          # several ranks: (global batch index, bytes) of every segment this rank wrote to its part file
         if per_read:
             self.gz = out_path.endswith(".gz")          # gzip members written by nb_gzip_members (parallel), see write_text
-            self.fh = open(out_path, "wb")
-            self.write_text(np.frombuffer(("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n").encode(), dtype=np.uint8))
+            header = np.frombuffer(("\t".join(["nimble_features", "nimble_score", "r1_CB", "r1_UB"] + COV_COLUMNS) + "\n").encode(), dtype=np.uint8)
+            if world == 1:
+                self.fh = open(out_path, "wb")
+                self.write_text(header)
+            else:      # every rank writes the rows of ITS batches to a part file; rank 0 concatenates them in batch order (merge.py)
+                self.part_path = f"{out_path}.rank{rank}.part"
+                self.fh = open(self.part_path, "wb")
+                self.header_bytes = self.encode_text(header)
 
-    def write_text(self, buf):
+    def write_text(self, buf, batch_index=None):
         """Append TSV text (uint8 array) to the per-read output, gzip-compressed when the output name ends in .gz."""
+        data = self.encode_text(buf)
+        self.fh.write(data)
+        if batch_index is not None and self.world > 1:
+            self.part_index.append((int(batch_index), len(data)))
+
+    def encode_text(self, buf):
+        """The bytes write_text appends for `buf`: the text itself, or its BGZF members for a .gz output."""
         if not self.gz:
-            self.fh.write(memoryview(buf))
-            return
+            return memoryview(np.ascontiguousarray(buf)).tobytes() if self.world > 1 else memoryview(buf)
         n = int(buf.shape[0])
         cap = n + (n >> 9) + 64 * ((n >> 20) + 1) + 64
         if self._gz_buf is None or self._gz_buf.shape[0] < cap:
@@ -200,7 +219,7 @@ class LibraryRun:
         out_len = ct.c_int64()
         buf = np.ascontiguousarray(buf)
         _lib.check(_lib.lib().nb_gzip_members(buf.ctypes.data, n, 4, self.gz_threads, self._gz_buf.ctypes.data, cap, ct.byref(out_len)))
-        self.fh.write(memoryview(self._gz_buf[:out_len.value]))
+        return memoryview(self._gz_buf[:out_len.value]).tobytes() if self.world > 1 else memoryview(self._gz_buf[:out_len.value])
 
     def refresh_classes(self):
         """Map newly interned classes to feature strings (nb_class_features: group_on naming + the feature-level filters of
@@ -232,22 +251,54 @@ class LibraryRun:
                           np.asarray(self.class_feat_id, dtype=np.int64))
         return self._snap
 
-    def finish(self):
+    def features_of_rows(self, rows):
+        """class bitset rows -> feature string per row, or None where a feature-count filter rejects the class (nb_class_features)."""
+        if rows.shape[0] == 0:
+            return []
+        feats, _, reasons = engine.class_features(rows, self._seq_feature, self._feature_names_c, len(self._feature_names), self.max_hits,
+                                                  self.multi_hits, self._name_bytes_max)
+        return [f if r == 0 else None for f, r in zip(feats, reasons.tolist())]
+
+    def finish(self, cdev=None):
+        """End of job. Several ranks (merge.py): per-read parts are concatenated by rank 0 in global batch order; bulk counts are
+        reduced with the digest-first dictionary agreement + one all-reduce and written by rank 0."""
         if self.per_read:
             self.fh.close()
+            if self.world > 1:
+                import torch.distributed as dist
+                from . import merge
+                index = [None] * self.world
+                dist.all_gather_object(index, self.part_index)
+                if self.rank == 0:
+                    merge.concat_parts_in_batch_order(index, [f"{self.out_path}.rank{r}.part" for r in range(self.world)], self.out_path, self.header_bytes)
+                dist.barrier()
+                os.remove(self.part_path)
             return
-        self.refresh_classes()
-        _, counts = self.ctx.classes()
-        for cid, cnt in enumerate(counts):
-            f = self.class_feature[cid]
+        if self.world > 1:
+            from . import merge
+            rows, counts = self.ctx.classes()
+            rows, counts = merge.reduce_class_counts_hashed(rows, counts, device=cdev)
+            if self.rank != 0:
+                return
+            feats = self.features_of_rows(rows)
+        else:
+            self.refresh_classes()
+            _, counts = self.ctx.classes()
+            feats = self.class_feature
+        for f, cnt in zip(feats, counts):
             if f is not None and cnt:
                 self.bulk[f] = self.bulk.get(f, 0) + int(cnt)
-        opener = gzip.open if self.out_path.endswith(".gz") else open
-        with opener(self.out_path, "wt") as fh:
-            fh.write("nimble_features\tnimble_score\n")
-            for f in sorted(self.bulk):
-                fh.write(f"{f}\t{self.bulk[f]}\n")
+        write_bulk_table(self.out_path, self.bulk)
         self.n_rows = len(self.bulk)
+
+
+def write_bulk_table(out_path, bulk):
+    """The legacy bulk shape (docs/SPEC.md §5, nimble/parse.py:39-57): header, then one row per distinct feature list, sorted."""
+    opener = gzip.open if out_path.endswith(".gz") else open
+    with opener(out_path, "wt") as fh:
+        fh.write("nimble_features\tnimble_score\n")
+        for f in sorted(bulk):
+            fh.write(f"{f}\t{bulk[f]}\n")
 
 
 class NativeWhitelist:
@@ -275,7 +326,7 @@ class NativeWhitelist:
             self._h = None
 
 
-def _write_per_read(run, snap, cls, info_raw, cov_raw, cb, cb_ok, umi):
+def _write_per_read(run, snap, cls, info_raw, cov_raw, cb, cb_ok, umi, batch_index=None):
     """Format this batch's rows in C++ (nb_format_tenx_rows) and append them to the run's TSV. `snap` = the run's class ->
     feature tables as of this batch (LibraryRun.snapshot(), taken on the main thread while the GPU was idle)."""
     feat_arr, n_feats, feat_max, cfid = snap
@@ -289,7 +340,7 @@ def _write_per_read(run, snap, cls, info_raw, cov_raw, cb, cb_ok, umi):
     _lib.check(_lib.lib().nb_format_tenx_rows(n, cls.ctypes.data, info_raw.ctypes.data, cov_raw.ctypes.data, feat_arr, n_feats,
                                               cb.ctypes.data, cb.shape[1], cb_ok.ctypes.data if cb_ok is not None else None, umi.ctypes.data,
                                               umi.shape[1], buf.ctypes.data, cap, ct.byref(out_len), ct.byref(n_rows)))
-    run.write_text(buf[:out_len.value])
+    run.write_text(buf[:out_len.value], batch_index)
     run.n_rows += n_rows.value
     if run.rows is not None:       # the same rows, as arrays, for the fused per-cell counting
         ok = ((info_raw >> 16) & 0xFF) == 0
@@ -329,6 +380,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
             _warn_library_options(lib)
         if not torch.cuda.is_available():
             raise RuntimeError("no MI355X/HIP device visible: nimble_amd has no CPU alignment path")
+        world, rank, device_id, cdev, own_group = _dist_setup(device_id)
         dev = torch.device("cuda", device_id)
         per_read = tenx is not None or is_bam      # BAM input carries CB/UB tags: one row per called template, as the reference
         if tenx is not None and is_bam:
@@ -339,7 +391,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         runs = []
         for lib, loaded_lib in zip(libs, loaded):
             suffix = "." + os.path.splitext(os.path.basename(lib))[0] if len(libs) > 1 else ""
-            runs.append(LibraryRun(loaded_lib, append_path_string(output, suffix), strand_filter, device_id, per_read))
+            runs.append(LibraryRun(loaded_lib, append_path_string(output, suffix), strand_filter, device_id, per_read, world, rank))
             runs[-1].gz_threads = max(1, int(num_cores))
             if report_output:
                 if not per_read:
@@ -398,6 +450,7 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         pending = pool.submit(fetch)
         host_out = [None, None]          # two sets of pinned result buffers: the writer thread reads one while the GPU fills the other
         turn = 0
+        batch_index = -1
         while True:
             with prof("wait for input"):
                 seq, mate, b1 = pending.result()
@@ -405,6 +458,10 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
             if n == 0:
                 break
             pending = pool.submit(fetch)
+            batch_index += 1
+            if batch_index % world != rank:   # several ranks: batches are dealt round-robin; every rank walks the whole input, aligns its share
+                total += n
+                continue
             with prof("H2D"):
                 words, max_len = _tight(seq)
                 d_reads = torch.from_numpy(words.view(np.int64)).to(dev, non_blocking=True)
@@ -439,23 +496,37 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
                         snap = run.snapshot()
                     write_jobs.append(writer.submit(_timed, prof, "TSV rows (writer thread)", _write_per_read, run, snap, h_class.numpy().view(np.uint32),
                                                     h_info.numpy().view(np.uint32), h_cov.numpy().view(np.uint64), b1["cb_fixed"], b1["cb_ok"],
-                                                    b1["umi"].copy()))   # (reader buffers are recycled two batches on)
+                                                    b1["umi"].copy(), batch_index))   # (reader buffers are recycled two batches on)
             total += n
         with prof("wait for writer"):
             for j in write_jobs:
                 j.result()
         writer.shutdown(wait=True)
         for run in runs:
-            run.finish()
-            if run.rows is not None:
-                nrows = run.rows.finish(None, run.feat_strings, run.report_path, report_threshold, report_disable_thresholding)
-                print(f"{run.lib.stem}: per-cell counts from {nrows} merged rows -> {run.report_path}")
+            run.finish(cdev)
             reasons = run.ctx.reasons()
-            print(f"{run.lib.stem}: {total} templates, {int(reasons[0])} called, {run.n_rows} output rows -> {run.out_path}")
-            print("  reasons: " + ", ".join(f"{engine.REASONS[i]}={int(v)}" for i, v in enumerate(reasons) if v))
+            n_rows = run.n_rows
+            if world > 1:
+                import torch.distributed as dist
+                t = torch.tensor(list(reasons) + [n_rows if run.per_read else 0], dtype=torch.int64, device=cdev)
+                dist.all_reduce(t)
+                reasons = t[:-1].cpu().numpy()
+                n_rows = int(t[-1]) if run.per_read else n_rows
+            if run.rows is not None:
+                nrows = _finish_fused(run, world, rank, report_threshold, report_disable_thresholding)
+                if rank == 0:
+                    print(f"{run.lib.stem}: per-cell counts from {nrows} merged rows -> {run.report_path}")
+            if rank == 0:
+                print(f"{run.lib.stem}: {total} templates, {int(reasons[0])} called, {n_rows} output rows -> {run.out_path}")
+                print("  reasons: " + ", ".join(f"{engine.REASONS[i]}={int(v)}" for i, v in enumerate(reasons) if v))
         if corrector:
             print(f"cell barcodes: {corrector.stats}")
-        print(f"Aligned {total} templates in {time.time() - t0:.2f} s")
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            if own_group:
+                dist.destroy_process_group()
+        print(f"Aligned {total} templates in {time.time() - t0:.2f} s" + (f" (rank {rank} of {world})" if world > 1 else ""))
         if os.environ.get("NB_PROFILE"):
             print("  stages: " + prof.report())
         pool.shutdown(wait=True)
@@ -475,6 +546,58 @@ def _warn_not_honoured(msg):
     accept such an option silently; the exit code stays 0 because the run itself is valid for untrimmed / unfiltered input)."""
     print(f"Warning -- not honoured: {msg}", file=sys.stderr)
     sys.stderr.flush()
+
+
+def _dist_setup(device_id):
+    """Several ranks (one process per GPU: `align --devices ...` or torchrun): (world, rank, device of this rank, device for the
+    collectives' buffers, whether this call created the process group). The group is created BEFORE the first GPU call of this
+    process. Backend: "nccl" (= RCCL over xGMI) unless NB_DIST_BACKEND says otherwise (gloo: ranks sharing one GPU, CPU tests)."""
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 1, 0, device_id, None, False
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    devices = [int(x) for x in os.environ["NB_DEVICES"].split(",")] if os.environ.get("NB_DEVICES") else None
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    dev = devices[rank % len(devices)] if devices else local % max(1, torch.cuda.device_count())
+    backend = os.environ.get("NB_DIST_BACKEND", "nccl")
+    own = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        own = True
+    cdev = torch.device("cuda", dev) if dist.get_backend() == "nccl" else torch.device("cpu")
+    return world, rank, dev, cdev, own
+
+
+def _finish_fused(run, world, rank, threshold, disable):
+    """Fused per-cell counts at the end of the job. One rank: reduce the accumulated rows. Several ranks: exchange the merged rows
+    by hash(cell barcode) mod world, reduce the own cells, rank 0 merges the per-rank outputs (merge.py)."""
+    if world == 1:
+        return run.rows.finish(None, run.feat_strings, run.report_path, threshold, disable)
+    import torch.distributed as dist
+    from . import merge
+    from .report import report_rows
+    if run.rows.umi_index:
+        raise NotImplementedError("UMI tags longer than 21 characters or outside ACGTN cannot be merged across ranks (rank-local ids)")
+    cols = [np.concatenate([p[j] for p in run.rows.parts]) if run.rows.parts else np.zeros(0, dtype=np.int64) for j in range(4)]
+    cbs, cb_ids, umi, fts, ft_ids, scores = merge.exchange_rows_by_cell(run.rows.cb_strings, cols[0], cols[1], run.feat_strings, cols[2], cols[3])
+    part = f"{run.report_path}.rank{rank}.part"
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):          # (the reducer's "Dropped n UMIs" line once per rank would be noise)
+        report_rows(cb_ids, umi, ft_ids, scores, cbs, fts, part, threshold, disable)
+    dist.barrier()
+    if rank == 0:
+        merge.merge_report_outputs([f"{run.report_path}.rank{r}.part" for r in range(world)], run.report_path)
+    dist.barrier()
+    os.remove(part)
+    return int(cols[0].shape[0])
 
 
 def _warn_library_options(lib):

@@ -17,6 +17,13 @@ for _i, _c in enumerate(b"ACGT"):
     _UMI_LUT[_c + 32] = _i
 
 
+_UMI_LUT_PAD = np.full(256, 7, dtype=np.uint64)     # as _UMI_LUT, but NUL (padding) = 5 and every other byte = 7 (not encodable)
+for _i, _c in enumerate(b"ACGTN"):
+    _UMI_LUT_PAD[_c] = _i
+    _UMI_LUT_PAD[_c + 32] = _i
+_UMI_LUT_PAD[0] = 5
+
+
 def encode_umis(umi):
     """[n, w] 'S1' array (w <= 21) -> uint64 codes, 3 bits per base (N kept distinct, as the raw UMI string is the key)."""
     umi = np.ascontiguousarray(umi)
@@ -91,12 +98,22 @@ class RowAccumulator:
         self.parts = []
 
     def umi_keys_of(self, umi):
-        """[n, w] 'S1' array -> int64 keys: the 3-bit code for fixed-width UMIs of <= 21 bases (FASTQ), else interned ids
-        (BAM tags: variable width, NUL padded)."""
+        """[n, w] 'S1' array -> int64 keys that identify the UMI STRING: 3 bits per character (A C G T N = 0..4, NUL padding = 5)
+        when no UMI has more than 21 significant characters and all of them are ACGTN — a function of the content alone, so
+        keys from different batches, and from different ranks, agree — else ids interned in this accumulator (rank-local)."""
         umi = np.ascontiguousarray(umi)
         n, w = umi.shape
-        if w <= 14 and not (umi.view(np.uint8) == 0).any():
-            return encode_umis(umi).astype(np.int64)
+        u8 = umi.view(np.uint8).reshape(n, w)
+        sig = w
+        while sig > 0 and not u8[:, sig - 1].any():      # trailing all-NUL columns (BAM tags are NUL padded to a fixed width)
+            sig -= 1
+        if sig <= 21:
+            codes = _UMI_LUT_PAD[u8[:, :sig]]
+            if not (codes == 7).any():
+                out = np.zeros(n, dtype=np.uint64)
+                for j in range(sig):
+                    out |= codes[:, j] << np.uint64(3 * j)
+                return out.astype(np.int64)
         flat = umi.view(f"S{w}").reshape(n)
         uniq, inv = np.unique(flat, return_inverse=True)
         ids = np.empty(uniq.shape[0], dtype=np.int64)

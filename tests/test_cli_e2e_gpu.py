@@ -69,9 +69,12 @@ def test_bulk_single_end(built, tmp_path):
     assert got == want and [l.split("\t")[0] for l in lines[1:]] == sorted(want)
 
 
-def test_paired_fastq_ragged_lengths(built, tmp_path):
+@pytest.mark.parametrize("batch_reads", [1 << 20, 25_000])
+def test_paired_fastq_ragged_lengths(built, tmp_path, batch_reads):
     """A biological pair from two FASTQ files with ragged read lengths: the readers pack each batch at the layout of its own
-    longest read and end a batch early before a longer one, independently for R1 and R2 — mates must stay paired."""
+    longest read and end a batch early before a longer one, independently for R1 and R2 — mates must stay paired. With
+    batch_reads = 25 000 the job has four outer batches and the early batch ends fall inside later ones: the top-up of the shorter
+    side then runs while the PREVIOUS batch is still being uploaded (it used to overwrite that batch's pinned buffers)."""
     lib_path, names, seqs, strs, lineage = make_library(tmp_path, intersect_level=1)
     n = 90_000
     rng = np.random.default_rng(21)
@@ -84,7 +87,8 @@ def test_paired_fastq_ragged_lengths(built, tmp_path):
     write_fastq(f1, [f"p{i}" for i in range(n)], r1)
     write_fastq(f2, [f"p{i}" for i in range(n)], r2)
     out = tmp_path / "pairs.tsv"
-    assert cli(["align", "--reference", str(lib_path), "--output", str(out), "--input", str(f1), str(f2), "-c", "4"]) == 0
+    from nimble_amd.align import align
+    assert align(str(lib_path), str(out), [str(f1), str(f2)], 4, "unstranded", "", None, batch_reads=batch_reads) == 0
     from oracle import oracle
     lib = library.Library(str(lib_path))
     c = lib.config
@@ -278,3 +282,40 @@ def test_bam_pairs_in_any_record_order_and_orphans(built, tmp_path):
             want.add("\t".join([",".join(feats), str(ora["mates"][i]), f"CELL{i:04d}", f"UMI{i % 90:03d}"] + [str(x) for x in ora["cov"][i]]))
     got = open(out).read().split("\n")[1:-1]
     assert len(got) == len(set(got)) and set(got) == want and len(want) > 300     # (row order follows the pairing order, not the file's)
+
+
+def test_two_ranks_equal_one_rank(built, tmp_path):
+    """`align --devices 0,0`: two processes (ranks sharing this box's one GPU, gloo for the collectives; on a multi-GPU node
+    `--devices 0,1` runs the same code over RCCL), batches dealt round-robin, end-of-job merge of nimble_amd/merge.py: the bulk
+    table, the per-read table (.gz) and the fused per-cell counts must be byte-identical to the single-process run."""
+    import subprocess
+    import sys
+    lib_path, names, seqs, strs, lineage = make_library(tmp_path)
+    rng = np.random.default_rng(15)
+    n = 9000
+    codes = synth.synth_reads(seqs, n, 100, seed=14)
+    r2 = [synth.codes_to_str(c) for c in codes]
+    wl = ["".join("ACGT"[c] for c in rng.integers(0, 4, 16)) for _ in range(60)]
+    umis = ["".join("ACGT"[c] for c in rng.integers(0, 4, 12)) for _ in range(n // 3)]
+    r1 = [wl[i] + umis[j] for i, j in zip(rng.integers(0, 20, n), rng.integers(0, len(umis), n))]
+    (tmp_path / "wl.txt").write_text("\n".join(wl) + "\n")
+    write_fastq(tmp_path / "R1.fastq", [f"q{i}" for i in range(n)], r1)
+    write_fastq(tmp_path / "R2.fastq", [f"q{i}" for i in range(n)], r2)
+    env = dict(os.environ, NB_BATCH_READS="1000", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+    def run(tag, extra):
+        bulk = [sys.executable, "-m", "nimble_amd", "align", "--reference", str(lib_path), "--output", str(tmp_path / f"{tag}_bulk.tsv"),
+                "--input", str(tmp_path / "R2.fastq")] + extra
+        tenx = [sys.executable, "-m", "nimble_amd", "align", "--reference", str(lib_path), "--output", str(tmp_path / f"{tag}_reads.tsv.gz"),
+                "--input", str(tmp_path / "R1.fastq"), str(tmp_path / "R2.fastq"), "--tenx", "--map", str(tmp_path / "wl.txt"),
+                "--report-output", str(tmp_path / f"{tag}_cells.tsv")] + extra
+        for cmd in (bulk, tenx):
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    run("one", [])
+    run("two", ["--devices", "0,0"])
+    for name in ("bulk.tsv", "reads.tsv.gz", "cells.tsv"):
+        a, b = open(tmp_path / f"one_{name}", "rb").read(), open(tmp_path / f"two_{name}", "rb").read()
+        assert a == b and len(a) > 500, name
+    assert len(gzip.open(tmp_path / "two_reads.tsv.gz", "rt").read().splitlines()) > 5000
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".part")]
