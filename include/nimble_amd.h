@@ -74,7 +74,8 @@ typedef struct nb_index_stats_t {
   int32_t k;
   int32_t uploaded;
   int32_t compact;        /* 1: compact cuckoo table (csrc/nb_internal.h), 0: wide table */
-  int32_t reserved;
+  int32_t words_internal; /* u64 words per class row on the device: sequences are renumbered internally so that every class of a
+                             component of <= 64 sequences lies in one word (csrc/nb_internal.h, ColDesc); callers never see it */
 } nb_index_stats_t;
 
 typedef struct nb_ctx nb_ctx;
@@ -242,7 +243,10 @@ int32_t nb_report_rows(int64_t n, const uint32_t* cb_ids, const uint64_t* umi_ke
                        int64_t n_cb, const char* const* cb_strings, int64_t n_feat, const char* const* feat_strings, double threshold,
                        int32_t disable_thresholding, const char* output_path, int64_t* status_out);
 
-/* name of the kernel nb_align_batch launches for this shape (for matching rocprofv3 kernel-trace rows) */
+/* kernels the LAST nb_align_batch on ctx launched, ';'-separated, dominant first (for matching rocprofv3 kernel-trace rows); the
+ * string is owned by ctx and valid until its next nb_align_batch */
+const char* nb_last_kernel_names(nb_ctx* ctx);
+/* the wave-per-read kernel nb_align_batch would launch for this shape, guessed from the shape alone (the table kind is chosen by size) */
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired);
 
 #ifdef __cplusplus

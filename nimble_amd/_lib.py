@@ -32,7 +32,7 @@ class NbIndexStats(ct.Structure):
     _fields_ = [
         ("n_seqs", ct.c_int64), ("n_kmers", ct.c_int64), ("n_canonical", ct.c_int64), ("table_slots", ct.c_int64), ("table_bytes", ct.c_int64),
         ("n_colours", ct.c_int64), ("words_per_row", ct.c_int64), ("device_bytes", ct.c_int64),
-        ("k", ct.c_int32), ("uploaded", ct.c_int32), ("compact", ct.c_int32), ("reserved", ct.c_int32),
+        ("k", ct.c_int32), ("uploaded", ct.c_int32), ("compact", ct.c_int32), ("words_internal", ct.c_int32),
     ]
 
 
@@ -65,6 +65,7 @@ SIGNATURES = {
     "nb_reasons_read": (ct.c_int32, [ct.c_void_p, c_i64p]),
     "nb_results_reset": (ct.c_int32, [ct.c_void_p, ct.c_void_p]),
     "nb_counts_device_ptr": (ct.c_int32, [ct.c_void_p, ct.POINTER(ct.c_void_p), c_i64p]),
+    "nb_last_kernel_names": (ct.c_char_p, [ct.c_void_p]),
     "nb_kernel_name": (ct.c_char_p, [ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32]),
     "nb_report_tsv": (ct.c_int32, [ct.c_char_p, ct.c_char_p, ct.c_double, ct.c_int32, c_i64p]),
     "nb_report_rows": (ct.c_int32, [ct.c_int64, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int64, ct.POINTER(ct.c_char_p),

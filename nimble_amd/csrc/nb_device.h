@@ -1,0 +1,288 @@
+// nb_device.h — device-side views, wave helpers and the context object shared by the kernel translation units
+// (nb_kernels.hip: one read per wave; nb_lane.hip: one read per lane). Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "nb_internal.h"
+#include "nb_wave.h"
+
+namespace nb {
+
+// ------------------------------------------------------------------------------------------------------------
+// device-side views
+struct DevIndex {
+  const Bucket* buckets;  // wide table (k > COMPACT_MAX_K): hash.n_buckets 32-byte buckets (nb_internal.h)
+  const CBucket* ctable;  // compact table (k <= COMPACT_MAX_K): chash.nb 16-byte buckets; exactly one of the two is set
+  const ColDesc* desc;    // n_colours 16-byte colour descriptors (internal sequence numbering)
+  const uint64_t* packed; // spans of the colours wider than one word
+  KmerHash hash;
+  CHash chash;
+  int W;                  // u64 words per colour row
+  int K;
+};
+
+// Compact table: both candidate buckets of a k-mer as they came back from memory (a = home, c = alternate; uint4 = {key0, pay0,
+// key1, pay1}) -> payload on the read strand (entry whose strand bit equals o = "the read's k-mer is the reverse complement of
+// the canonical key") and on the reverse-complement strand. Entries of the home bucket must carry which = 0, those of the
+// alternate bucket which = 1 (nb_internal.h: that is what makes the match exact). 8 compares + 8 selects, no loop.
+__device__ __forceinline__ void compact_match(const uint4& a, const uint4& c, uint32_t want, uint32_t o, bool valid, uint32_t& payF, uint32_t& payR) {
+  const uint32_t wF1 = want | o, wR1 = wF1 ^ 1u, wF2 = wF1 | 2u, wR2 = wR1 | 2u;
+  uint32_t f = PAY_ABSENT, r = PAY_ABSENT;
+  f = a.x == wF1 ? a.y : f; r = a.x == wR1 ? a.y : r;
+  f = a.z == wF1 ? a.w : f; r = a.z == wR1 ? a.w : r;
+  f = c.x == wF2 ? c.y : f; r = c.x == wR2 ? c.y : r;
+  f = c.z == wF2 ? c.w : f; r = c.z == wR2 ? c.w : r;
+  payF = valid ? f : PAY_ABSENT; payR = valid ? r : PAY_ABSENT;
+}
+__device__ __forceinline__ uint4 load_cbucket(const CBucket* __restrict__ T, uint32_t b) { return *reinterpret_cast<const uint4*>(&T[b]); }
+
+// One bucket probe for one lane. Returns true on a hit and fills p0/p1; `more` = the bucket is flagged OVERFLOW (the key
+// may live in the next bucket).
+__device__ __forceinline__ bool probe_bucket(const Bucket* __restrict__ B, uint32_t b, uint64_t canon, uint32_t& p0, uint32_t& p1, bool& more) {
+  const uint4* kp = reinterpret_cast<const uint4*>(&B[b]);
+  const uint4 a = kp[0], c = kp[1];
+  const uint64_t k0 = ((uint64_t)a.y << 32) | a.x, k1 = ((uint64_t)c.y << 32) | c.x;
+  const bool m0 = (k0 & KEY_MASK) == canon, m1 = k1 == canon;
+  more = (k0 >> 63) != 0;
+  p0 = m0 ? a.z : c.z; p1 = m0 ? a.w : c.w;
+  return m0 || m1;
+}
+
+struct DevClasses {
+  unsigned long long* keys;    // cap slots, 0 = free
+  unsigned int* ids;           // cap slots, id+1 once published, 0 = not yet, 0xFFFFFFFF = overflow
+  unsigned long long* rows;    // max_classes * W
+  unsigned long long* counts;  // max_classes
+  unsigned int* spans;         // max_classes: first non-zero word | last non-zero word << 16 of rows[id] (written before the id is
+                               // published): lets one lane verify a row it holds as (word index, words) without reading all W words
+  unsigned int* n_classes;     // allocated ids
+  unsigned int* err;           // bit0: class table overflow, bit1: spin timeout
+  unsigned long long* reasons; // NB_NUM_REASONS
+  unsigned int cap_log2;
+  unsigned int max_classes;
+};
+
+struct BatchArgs {
+  const uint64_t* reads; const uint16_t* lens; int max_len; int stride; int nwb;     // r1
+  const uint64_t* mates; const uint16_t* mate_lens; int mate_max_len; int mstride; int mnwb;  // r2 (optional)
+  long long n;
+  const uint32_t* n_dev;     // optional: the number of templates lives on the device (redo list of the lane-per-read path); n is then an upper bound
+  uint32_t* out_class; uint32_t* out_info; uint64_t* out_cov;
+  const uint16_t* pct_min;   // pct_min[L] = smallest cov with (double)cov/(double)L >= score_percent, L in 0..max(max_len,mate_max_len)
+  int pct_fixed;             // pct_min[max_len], used when every read has length max_len (lens == NULL): no table load
+  int score_threshold, score_filter, num_mismatches, discard_multiple, intersect_level, require_valid_pair, strand_filter;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// wave-level helpers (wave64)
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v) {  // lane 0's value to every lane
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z ^= z >> 33; z *= 0xff51afd7ed558ccdull; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull; z ^= z >> 33; return z;
+}
+
+// reverse complement of a k-mer held LSB-first (nb_internal.h encoding)
+__device__ __forceinline__ uint64_t rc_kmer(uint64_t x, int K) {
+  uint64_t v = __brevll(~x);
+  v = ((v & 0x5555555555555555ull) << 1) | ((v >> 1) & 0x5555555555555555ull);
+  return v >> (64 - 2 * K);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// multiword bit masks over k-mer positions (NR words, wave-uniform values)
+template <int NR> struct Mask { uint64_t w[NR]; };
+
+// first set bit at a position p >= from with (p - from) % 3 == 0, or -1          (SPEC §3 seed(), SCAN_STRIDE = 3)
+template <int NR> __device__ __forceinline__ int ffs_stride3(const Mask<NR>& m, int from) {
+  const uint64_t PAT = 0x9249249249249249ull;  // bits t with t % 3 == 0
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) {
+    const int base = wi * 64;
+    if (from < base + 64) {
+      uint64_t v = m.w[wi];
+      const int res = ((from % 3) - (wi % 3) + 3) % 3;  // want t with (base + t) % 3 == from % 3; 64 % 3 == 1
+      v &= PAT << res;
+      if (from > base) v &= ~0ull << (from - base);
+      if (v) return base + __builtin_ctzll(v);
+    }
+  }
+  return -1;
+}
+// first ZERO bit at a position >= from (caller guarantees one exists below NR*64)
+template <int NR> __device__ __forceinline__ int ffz_from(const Mask<NR>& m, int from) {
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) {
+    const int base = wi * 64;
+    if (from < base + 64) {
+      uint64_t v = ~m.w[wi];
+      if (from > base) v &= ~0ull << (from - base);
+      if (v) return base + __builtin_ctzll(v);
+    }
+  }
+  return NR * 64;
+}
+// highest ZERO bit at a position <= from (bit 0 of the masks passed here is always zero)
+template <int NR> __device__ __forceinline__ int flz_upto(const Mask<NR>& m, int from) {
+#pragma unroll
+  for (int wi = NR - 1; wi >= 0; --wi) {
+    const int base = wi * 64;
+    if (from >= base) {
+      uint64_t v = ~m.w[wi];
+      if (from < base + 63) v &= (2ull << (from - base)) - 1;
+      if (v) return base + 63 - __builtin_clzll(v);
+    }
+  }
+  return 0;
+}
+template <int NR> __device__ __forceinline__ void set_range(Mask<NR>& m, int lo, int hi) {  // inclusive, lo <= hi
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) {
+    const int base = wi * 64;
+    if (lo < base + 64 && hi >= base) {
+      const int a = lo > base ? lo - base : 0, b = hi < base + 63 ? hi - base : 63;
+      const uint64_t hi_mask = (b == 63) ? ~0ull : ((2ull << b) - 1);
+      m.w[wi] |= hi_mask & (~0ull << a);
+    }
+  }
+}
+template <int NR> __device__ __forceinline__ bool any_set(const Mask<NR>& m) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) v |= m.w[wi];
+  return v != 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// SPEC §3 on masks, exact mode (no tolerated mismatch). H = k-mer present, R = present and the next read base is a
+// right extension, LX = present and the previous read base is a left extension. Positions are in walk order
+// (position 0 = first k-mer of the sequence being mapped). Returns coverage (0 = NONE) and the visited positions.
+template <int NR>
+__device__ __forceinline__ int walk_masks(const Mask<NR>& H, const Mask<NR>& R, const Mask<NR>& LX, int L, int K, Mask<NR>& V) {
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) V.w[wi] = 0;
+  const int last = L - K;
+  int p = ffs_stride3<NR>(H, 0);
+  if (p < 0) return 0;
+  int cov = 0;
+  if (p >= L / 5 && p > 0) {               // left extension: consecutive LX bits going down from p
+    const int z = flz_upto<NR>(LX, p);
+    const int t = p - z;
+    if (t > 0) { cov += t; set_range<NR>(V, p - t, p - 1); }
+  }
+  for (;;) {
+    const int e = ffz_from<NR>(R, p);      // run p..e
+    cov += K + (e - p);
+    set_range<NR>(V, p, e);
+    const int b = e + K;
+    if (b > last) break;
+    p = ffs_stride3<NR>(H, b);
+    if (p < 0) break;
+  }
+  return cov;
+}
+
+// highest set bit at a position i <= from with (from - i) % 3 == 0, or -1
+template <int NR> __device__ __forceinline__ int fls_stride3_down(const Mask<NR>& m, int from) {
+  const uint64_t PAT = 0x9249249249249249ull;
+#pragma unroll
+  for (int wi = NR - 1; wi >= 0; --wi) {
+    const int base = wi * 64;
+    if (from >= base) {
+      uint64_t v = m.w[wi];
+      const int res = ((from % 3) - (wi % 3) + 3) % 3;
+      v &= PAT << res;
+      if (from < base + 63) v &= (2ull << (from - base)) - 1;
+      if (v) return base + 63 - __builtin_clzll(v);
+    }
+  }
+  return -1;
+}
+
+// SPEC §3 for the REVERSE-COMPLEMENT strand, evaluated directly on masks indexed by read position i (rc position
+// j = P-1-i): the walk advances towards lower i, "left" is towards higher i. Same arithmetic as walk_masks on the
+// bit-reversed masks, without reversing them. H/R/LX are the rc strand's facts at read position i.
+template <int NR>
+__device__ __forceinline__ int walk_masks_down(const Mask<NR>& H, const Mask<NR>& R, const Mask<NR>& LX, int L, int K, Mask<NR>& V) {
+#pragma unroll
+  for (int wi = 0; wi < NR; ++wi) V.w[wi] = 0;
+  const int last = L - K;                       // = P-1
+  int ip = fls_stride3_down<NR>(H, last);       // rc position 0 is read position last
+  if (ip < 0) return 0;
+  int cov = 0;
+  const int pj = last - ip;
+  if (pj >= L / 5 && pj > 0) {                  // left extension: consecutive LX bits going UP from ip
+    const int z = ffz_from<NR>(LX, ip);
+    const int t = z - ip;
+    if (t > 0) { cov += t; set_range<NR>(V, ip + 1, ip + t); }
+  }
+  for (;;) {
+    const int ei = flz_upto<NR>(R, ip);         // run ip .. ei (downwards)
+    cov += K + (ip - ei);
+    set_range<NR>(V, ei, ip);
+    const int bj = (last - ei) + K;
+    if (bj > last) break;
+    ip = fls_stride3_down<NR>(H, last - bj);
+    if (ip < 0) break;
+  }
+  return cov;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// SPEC §4 checks 1-2 on a mapped strand (cheap part): returns 0 if it may be valid, else the reason.
+__device__ __forceinline__ int cheap_reason_p(int cov, int pmin, const BatchArgs& a) {
+  if (cov == 0) return NB_NO_HIT;
+  if (cov < a.score_threshold) return NB_SCORE_THRESHOLD;
+  if (cov < pmin) return NB_SCORE_PERCENT;
+  return 0;
+}
+__device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) { return cheap_reason_p(cov, (int)a.pct_min[L], a); }
+
+// ------------------------------------------------------------------------------------------------------------
+// host side shared by the translation units
+void set_error(const std::string& msg);
+#define NB_HIP(call)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) { nb::set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return NB_ERR_HIP; } \
+  } while (0)
+
+struct LaneLists {
+  uint32_t* rc_list;      // reads to map in reverse-complement orientation (pass 1 of the lane-per-read path)
+  uint32_t* redo_list;    // reads for the wave-per-read kernel
+  uint32_t* counters;     // [0] = entries in rc_list, [1] = entries in redo_list
+};
+}  // namespace nb
+
+struct nb_ctx;
+namespace nb {
+// nb_lane.hip: both lane-per-read passes of one batch, then gather of the redo reads; nb_lane_scatter puts their results back
+int launch_lane(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
+int launch_lane_gather(nb_ctx* c, const BatchArgs& a, const LaneLists& ll, uint64_t* redo_reads, uint16_t* redo_lens, hipStream_t s);
+int launch_lane_scatter(nb_ctx* c, const BatchArgs& a, const LaneLists& ll, const uint32_t* redo_out, hipStream_t s);
+}  // namespace nb
+
+struct nb_index { nb::HostIndex* h; };
+
+struct nb_ctx {
+  int device = 0;
+  int n_cu = 256;
+  // bound index (device copies)
+  nb::Bucket* d_slots = nullptr; nb::CBucket* d_ctable = nullptr; bool compact = false; nb::CHash chash{}; nb::ColDesc* d_desc = nullptr; uint64_t* d_packed = nullptr; nb::KmerHash hash{}; int W = 0 /* words per class row, INTERNAL numbering */, W_ext = 0, K = 0, n_seqs = 0; int64_t index_bytes = 0;
+  std::vector<int32_t> inv_perm;   // internal bit -> original sequence index (-1 = padding): class rows leave the library in original numbering
+  // class table
+  nb::DevClasses ct{}; nb::DevClasses* d_ct = nullptr; int64_t max_classes = 0;
+  // worklists of the lane-per-read path (nb_lane.hip): reads to map in reverse-complement orientation, reads for the wave-per-read kernel
+  uint32_t* d_lists = nullptr; int64_t lists_cap = 0; uint32_t* d_list_counters = nullptr; int max_desc_nw = 0;
+  uint64_t* d_redo_reads = nullptr; int64_t redo_words_cap = 0; uint16_t* d_redo_lens = nullptr; uint32_t* d_redo_out = nullptr;   // gathered redo reads + their results (4 u32 per read)
+  std::string last_kernels;        // kernels launched by the last nb_align_batch (nb_last_kernel_names)   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
+  // score_percent table
+  uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0; std::vector<uint16_t> pct_host;
+};
+

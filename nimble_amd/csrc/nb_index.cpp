@@ -154,22 +154,58 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     for (uint64_t t = col_off[c]; t < col_off[c + 1]; ++t) row[pool[t] >> 6] |= 1ull << (pool[t] & 63);
   }
 
-  // 3b. device form of the colours: span descriptors + packed spans for the wide ones (nb_internal.h, ColDesc)
-  ix->desc.resize(n_col);
-  ix->packed.assign(1, 0ull);
-  for (uint32_t id = 0; id < n_col; ++id) {
-    const uint64_t* row = ix->eq_rows.data() + (size_t)id * (size_t)ix->words;
-    int first = 0, lastw = ix->words - 1;
-    while (first < ix->words && row[first] == 0) ++first;
-    while (lastw > first && row[lastw] == 0) --lastw;
-    ColDesc d{}; d.w0 = (uint32_t)first; d.nw = (uint32_t)(lastw - first + 1); d.size = ix->eq_sizes[id];
-    d.m0 = row[first]; d.m1 = d.nw > 1 ? row[first + 1] : 0ull; d.off = 0;
-    if (d.nw > 2) {
-      if (ix->packed.size() + d.nw > 0xFFFFFFFFull) { delete ix; set_error("nb_index_build: packed colour spans exceed 2^32 words"); return NB_ERR_UNSUPPORTED; }
-      d.off = (uint32_t)ix->packed.size();
-      ix->packed.insert(ix->packed.end(), row + first, row + lastw + 1);
+  // 3a. internal sequence numbering (nb_internal.h, ColDesc): connected components of "two sequences share a k-mer" (union-find
+  //     over the colours' member lists), in order of their smallest member; a component of <= 64 sequences never straddles a word
+  //     boundary, a larger one starts at a boundary. Every class then lies inside its component's words.
+  {
+    std::vector<uint32_t> parent((size_t)n_seqs); std::iota(parent.begin(), parent.end(), 0u);
+    auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    for (uint32_t c = 0; c < n_col; ++c) {
+      const uint32_t r0 = find(pool[col_off[c]]);
+      for (uint64_t t = col_off[c] + 1; t < col_off[c + 1]; ++t) { const uint32_t r = find(pool[t]); if (r != r0) parent[r] = r0; }
     }
-    ix->desc[id] = d;
+    std::vector<std::vector<uint32_t>> comps; std::vector<int32_t> comp_of((size_t)n_seqs, -1);
+    for (int sidx = 0; sidx < n_seqs; ++sidx) {
+      const uint32_t r = find((uint32_t)sidx);
+      if (comp_of[r] < 0) { comp_of[r] = (int32_t)comps.size(); comps.emplace_back(); }
+      comps[(size_t)comp_of[r]].push_back((uint32_t)sidx);
+    }
+    ix->perm.assign((size_t)n_seqs, -1);
+    int64_t bit = 0;
+    for (const auto& comp : comps) {
+      const int64_t sz = (int64_t)comp.size();
+      if (sz > 64 || (bit & 63) + sz > 64) bit = (bit + 63) & ~63ll;
+      for (uint32_t sidx : comp) ix->perm[sidx] = (int32_t)bit++;
+    }
+    ix->words_dev = (int)((bit + 63) >> 6);
+    if (ix->words_dev < 1) ix->words_dev = 1;
+    ix->inv_perm.assign((size_t)ix->words_dev * 64, -1);
+    for (int sidx = 0; sidx < n_seqs; ++sidx) ix->inv_perm[(size_t)ix->perm[(size_t)sidx]] = sidx;
+  }
+
+  // 3b. device form of the colours: 16-byte descriptors in internal numbering + packed spans for the classes wider than a word
+  ix->desc.resize(n_col);
+  ix->packed.assign(2, 0ull);
+  {
+    std::vector<uint64_t> span;
+    for (uint32_t c = 0; c < n_col; ++c) {
+      const uint32_t id = remap[c];
+      uint32_t lo = 0xFFFFFFFFu, hi = 0;
+      for (uint64_t t = col_off[c]; t < col_off[c + 1]; ++t) { const uint32_t w = (uint32_t)ix->perm[pool[t]] >> 6; lo = std::min(lo, w); hi = std::max(hi, w); }
+      span.assign((size_t)(hi - lo + 1), 0ull);
+      for (uint64_t t = col_off[c]; t < col_off[c + 1]; ++t) { const uint32_t b = (uint32_t)ix->perm[pool[t]]; span[(b >> 6) - lo] |= 1ull << (b & 63); }
+      ColDesc d{}; d.w0 = lo; d.nw = hi - lo + 1;
+      ix->max_desc_nw = std::max(ix->max_desc_nw, (int)d.nw);
+      if (d.nw == 1) d.m = span[0];
+      else {
+        if (ix->packed.size() & 1) ix->packed.push_back(0ull);                       // spans start 16-byte aligned
+        if (ix->packed.size() + d.nw > 0xFFFFFFFFull) { delete ix; set_error("nb_index_build: packed colour spans exceed 2^32 words"); return NB_ERR_UNSUPPORTED; }
+        d.m = (uint64_t)ix->packed.size();
+        ix->packed.insert(ix->packed.end(), span.begin(), span.end());
+      }
+      ix->desc[id] = d;
+    }
+    if (ix->packed.size() & 1) ix->packed.push_back(0ull);
   }
 
   // 4. unitig-interior flags (SPEC §2, local rule). recs is sorted by k-mer.
@@ -210,8 +246,16 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     }
   }
   const int64_t n_canon = (int64_t)canons.size();
-  const char* force = std::getenv("NB_TABLE");       // "wide" forces the 16-byte-slot table (tests / A-B measurements), default = compact when k allows
-  if (k <= COMPACT_MAX_K && !(force && std::string(force) == "wide")) {
+  // Table kind. The compact cuckoo table reads TWO random 16-byte buckets per lookup: that wins while the table stays (nearly) resident in
+  // the 4 MiB L2s (measured on MI355X, profiles/r02_tuning_notes.md: c2 2.9 MB 15.4 vs 16.4 ms, c3 4.7 MB 107 vs 124 ms) and loses once
+  // the lookups go to the fabric, which serves a fixed ~55-60 G requests/s whatever the table size (c5: 26 MB, 500 vs 314 ms with the
+  // one-line-per-lookup wide table). NB_TABLE=wide / compact forces a kind (tests, A/B runs).
+  const char* force = std::getenv("NB_TABLE");
+  int64_t n_entries_est = 0;
+  for (const Canon& c : canons) n_entries_est += (c.pay[0] != PAY_ABSENT) + (c.pay[1] != PAY_ABSENT);
+  const bool fits = (double)n_entries_est / COMPACT_LOAD * 8.0 <= (double)COMPACT_MAX_BYTES;
+  const bool want_compact = force ? std::string(force) == "compact" || (std::string(force) != "wide" && fits) : fits;
+  if (k <= COMPACT_MAX_K && want_compact) {
     // 5a. compact table: (2,2) partial-key cuckoo, one entry per (canonical k-mer, strand) present (nb_internal.h)
     int64_t n_entries = 0;
     for (const Canon& c : canons) n_entries += (c.pay[0] != PAY_ABSENT) + (c.pay[1] != PAY_ABSENT);

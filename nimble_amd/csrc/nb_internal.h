@@ -82,6 +82,7 @@ struct CBucket { CEntry e[2]; };
 static_assert(sizeof(CBucket) == 16, "compact bucket must be 16 bytes");
 constexpr int COMPACT_MAX_K = 23;                       // hb <= 14: nb >= 2^16 buckets (1 MiB) at the most
 constexpr double COMPACT_LOAD = 0.85;                   // (2,2) cuckoo threshold is 0.897
+constexpr int64_t COMPACT_MAX_BYTES = 8ll << 20;        // larger tables are not L2-resident: the one-line-per-lookup wide table wins there (nb_index.cpp)
 constexpr uint32_t CKEY_EMPTY = 0xFFFFFFFFu;
 struct CHash { uint32_t a, c, nb, nbm1, hb, himask; };
 struct CProbe { uint32_t want, b1, b2; };               // want = rem << 2 (which = 0, strand = 0)
@@ -107,18 +108,19 @@ NB_HD inline CProbe compact_probe(uint64_t canon, const CHash& h) {
   return p;
 }
 
-// A colour (equivalence class of the graph) on the device: the span of u64 words of its bitset that can be non-zero,
-// with the first two words inline. Most classes of a gene-family library live inside one locus, i.e. inside one or two
-// words, so the intersection of a read's classes usually needs nothing but these 32 bytes per k-mer position; wider
-// classes keep their span in `packed` at [off, off + nw). Loaded with two dwordx4.
+// A colour (equivalence class of the graph) on the device, 16 bytes, one dwordx4. Bit positions are INTERNAL sequence numbers: the
+// index builder renumbers the sequences so that every connected component of the "share a k-mer" relation (a locus, for a
+// gene-family library) starts at a 64-bit word boundary or lies inside one word (nb_index.cpp, step 3a). A class is a subset of one
+// component, so classes of components of <= 64 sequences occupy exactly ONE word: nw == 1 and `m` is that word — intersecting a
+// read's classes then needs nothing but these 16 bytes per k-mer position. Classes of larger components keep their nw words in
+// `packed` at [(uint32_t)m, +nw), 16-byte aligned. Rows of the class table are in internal numbering too; the C-ABI converts them
+// back (nb_classes_read), so callers only ever see original sequence indices.
 struct ColDesc {
-  uint32_t w0;     // first word of the span
+  uint32_t w0;     // first word of the span (internal numbering)
   uint32_t nw;     // words in the span (>= 1)
-  uint32_t off;    // index into packed[] of the span (valid when nw > 2)
-  uint32_t size;   // members (popcount)
-  uint64_t m0, m1; // words w0 and w0 + 1
+  uint64_t m;      // nw == 1: the word; nw > 1: index into packed[] of the span
 };
-static_assert(sizeof(ColDesc) == 32, "descriptor must be 32 bytes");
+static_assert(sizeof(ColDesc) == 16, "descriptor must be 16 bytes");
 
 inline uint32_t make_payload(uint32_t colour, uint32_t lext, uint32_t rext, uint32_t r_int, uint32_t l_int) {
   return (colour << 10) | (l_int << 9) | (r_int << 8) | (lext << 4) | rext;
@@ -139,7 +141,11 @@ struct HostIndex {
   CHash chash{};
   std::vector<CBucket> ctable;        // chash.nb buckets
   int n_seqs = 0;
-  int words = 0;                      // u64 words per colour row
+  int words = 0;                      // u64 words per colour row in ORIGINAL numbering = ceil(n_seqs / 64): eq_rows, the C-ABI
+  int words_dev = 0;                  // u64 words per row in INTERNAL numbering (device descriptors, class table rows)
+  int max_desc_nw = 1;                // widest class span in words (1 = every class inside one word: the lane-per-read kernels apply)
+  std::vector<int32_t> perm;          // original sequence index -> internal bit position
+  std::vector<int32_t> inv_perm;      // internal bit position -> original sequence index, -1 = padding
   KmerHash hash{};                    // hash.n_buckets buckets of SLOTS_PER_BUCKET slots
   int64_t n_kmers = 0;                // distinct stranded k-mers
   int64_t n_canonical = 0;

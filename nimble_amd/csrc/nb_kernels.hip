@@ -22,231 +22,11 @@
 #include <cstring>
 #include <string>
 
-#include "nb_internal.h"
-#include "nb_wave.h"
+
+#include "nb_device.h"
 
 namespace nb {
 
-// ------------------------------------------------------------------------------------------------------------
-// device-side views
-struct DevIndex {
-  const Bucket* buckets;  // wide table (k > COMPACT_MAX_K): hash.n_buckets 32-byte buckets (nb_internal.h)
-  const CBucket* ctable;  // compact table (k <= COMPACT_MAX_K): chash.nb 16-byte buckets; exactly one of the two is set
-  const ColDesc* desc;    // n_colours colour descriptors (span + first two words)
-  const uint64_t* packed; // spans of the colours wider than two words
-  KmerHash hash;
-  CHash chash;
-  int W;                  // u64 words per colour row
-  int K;
-};
-
-// Compact table: both candidate buckets of a k-mer as they came back from memory (a = home, c = alternate; uint4 = {key0, pay0,
-// key1, pay1}) -> payload on the read strand (entry whose strand bit equals o = "the read's k-mer is the reverse complement of
-// the canonical key") and on the reverse-complement strand. Entries of the home bucket must carry which = 0, those of the
-// alternate bucket which = 1 (nb_internal.h: that is what makes the match exact). 8 compares + 8 selects, no loop.
-__device__ __forceinline__ void compact_match(const uint4& a, const uint4& c, uint32_t want, uint32_t o, bool valid, uint32_t& payF, uint32_t& payR) {
-  const uint32_t wF1 = want | o, wR1 = wF1 ^ 1u, wF2 = wF1 | 2u, wR2 = wR1 | 2u;
-  uint32_t f = PAY_ABSENT, r = PAY_ABSENT;
-  f = a.x == wF1 ? a.y : f; r = a.x == wR1 ? a.y : r;
-  f = a.z == wF1 ? a.w : f; r = a.z == wR1 ? a.w : r;
-  f = c.x == wF2 ? c.y : f; r = c.x == wR2 ? c.y : r;
-  f = c.z == wF2 ? c.w : f; r = c.z == wR2 ? c.w : r;
-  payF = valid ? f : PAY_ABSENT; payR = valid ? r : PAY_ABSENT;
-}
-__device__ __forceinline__ uint4 load_cbucket(const CBucket* __restrict__ T, uint32_t b) { return *reinterpret_cast<const uint4*>(&T[b]); }
-
-// One bucket probe for one lane. Returns true on a hit and fills p0/p1; `more` = the bucket is flagged OVERFLOW (the key
-// may live in the next bucket).
-__device__ __forceinline__ bool probe_bucket(const Bucket* __restrict__ B, uint32_t b, uint64_t canon, uint32_t& p0, uint32_t& p1, bool& more) {
-  const uint4* kp = reinterpret_cast<const uint4*>(&B[b]);
-  const uint4 a = kp[0], c = kp[1];
-  const uint64_t k0 = ((uint64_t)a.y << 32) | a.x, k1 = ((uint64_t)c.y << 32) | c.x;
-  const bool m0 = (k0 & KEY_MASK) == canon, m1 = k1 == canon;
-  more = (k0 >> 63) != 0;
-  p0 = m0 ? a.z : c.z; p1 = m0 ? a.w : c.w;
-  return m0 || m1;
-}
-
-struct DevClasses {
-  unsigned long long* keys;    // cap slots, 0 = free
-  unsigned int* ids;           // cap slots, id+1 once published, 0 = not yet, 0xFFFFFFFF = overflow
-  unsigned long long* rows;    // max_classes * W
-  unsigned long long* counts;  // max_classes
-  unsigned int* n_classes;     // allocated ids
-  unsigned int* err;           // bit0: class table overflow, bit1: spin timeout
-  unsigned long long* reasons; // NB_NUM_REASONS
-  unsigned int cap_log2;
-  unsigned int max_classes;
-};
-
-struct BatchArgs {
-  const uint64_t* reads; const uint16_t* lens; int max_len; int stride; int nwb;     // r1
-  const uint64_t* mates; const uint16_t* mate_lens; int mate_max_len; int mstride; int mnwb;  // r2 (optional)
-  long long n;
-  uint32_t* out_class; uint32_t* out_info; uint64_t* out_cov;
-  const uint16_t* pct_min;   // pct_min[L] = smallest cov with (double)cov/(double)L >= score_percent, L in 0..max(max_len,mate_max_len)
-  int pct_fixed;             // pct_min[max_len], used when every read has length max_len (lens == NULL): no table load
-  int score_threshold, score_filter, num_mismatches, discard_multiple, intersect_level, require_valid_pair, strand_filter;
-};
-
-// ------------------------------------------------------------------------------------------------------------
-// wave-level helpers (wave64)
-__device__ __forceinline__ uint64_t bcast_u64(uint64_t v) {  // lane 0's value to every lane
-  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z ^= z >> 33; z *= 0xff51afd7ed558ccdull; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull; z ^= z >> 33; return z;
-}
-
-// reverse complement of a k-mer held LSB-first (nb_internal.h encoding)
-__device__ __forceinline__ uint64_t rc_kmer(uint64_t x, int K) {
-  uint64_t v = __brevll(~x);
-  v = ((v & 0x5555555555555555ull) << 1) | ((v >> 1) & 0x5555555555555555ull);
-  return v >> (64 - 2 * K);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// multiword bit masks over k-mer positions (NR words, wave-uniform values)
-template <int NR> struct Mask { uint64_t w[NR]; };
-
-// first set bit at a position p >= from with (p - from) % 3 == 0, or -1          (SPEC §3 seed(), SCAN_STRIDE = 3)
-template <int NR> __device__ __forceinline__ int ffs_stride3(const Mask<NR>& m, int from) {
-  const uint64_t PAT = 0x9249249249249249ull;  // bits t with t % 3 == 0
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) {
-    const int base = wi * 64;
-    if (from < base + 64) {
-      uint64_t v = m.w[wi];
-      const int res = ((from % 3) - (wi % 3) + 3) % 3;  // want t with (base + t) % 3 == from % 3; 64 % 3 == 1
-      v &= PAT << res;
-      if (from > base) v &= ~0ull << (from - base);
-      if (v) return base + __builtin_ctzll(v);
-    }
-  }
-  return -1;
-}
-// first ZERO bit at a position >= from (caller guarantees one exists below NR*64)
-template <int NR> __device__ __forceinline__ int ffz_from(const Mask<NR>& m, int from) {
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) {
-    const int base = wi * 64;
-    if (from < base + 64) {
-      uint64_t v = ~m.w[wi];
-      if (from > base) v &= ~0ull << (from - base);
-      if (v) return base + __builtin_ctzll(v);
-    }
-  }
-  return NR * 64;
-}
-// highest ZERO bit at a position <= from (bit 0 of the masks passed here is always zero)
-template <int NR> __device__ __forceinline__ int flz_upto(const Mask<NR>& m, int from) {
-#pragma unroll
-  for (int wi = NR - 1; wi >= 0; --wi) {
-    const int base = wi * 64;
-    if (from >= base) {
-      uint64_t v = ~m.w[wi];
-      if (from < base + 63) v &= (2ull << (from - base)) - 1;
-      if (v) return base + 63 - __builtin_clzll(v);
-    }
-  }
-  return 0;
-}
-template <int NR> __device__ __forceinline__ void set_range(Mask<NR>& m, int lo, int hi) {  // inclusive, lo <= hi
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) {
-    const int base = wi * 64;
-    if (lo < base + 64 && hi >= base) {
-      const int a = lo > base ? lo - base : 0, b = hi < base + 63 ? hi - base : 63;
-      const uint64_t hi_mask = (b == 63) ? ~0ull : ((2ull << b) - 1);
-      m.w[wi] |= hi_mask & (~0ull << a);
-    }
-  }
-}
-template <int NR> __device__ __forceinline__ bool any_set(const Mask<NR>& m) {
-  uint64_t v = 0;
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) v |= m.w[wi];
-  return v != 0;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// SPEC §3 on masks, exact mode (no tolerated mismatch). H = k-mer present, R = present and the next read base is a
-// right extension, LX = present and the previous read base is a left extension. Positions are in walk order
-// (position 0 = first k-mer of the sequence being mapped). Returns coverage (0 = NONE) and the visited positions.
-template <int NR>
-__device__ __forceinline__ int walk_masks(const Mask<NR>& H, const Mask<NR>& R, const Mask<NR>& LX, int L, int K, Mask<NR>& V) {
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) V.w[wi] = 0;
-  const int last = L - K;
-  int p = ffs_stride3<NR>(H, 0);
-  if (p < 0) return 0;
-  int cov = 0;
-  if (p >= L / 5 && p > 0) {               // left extension: consecutive LX bits going down from p
-    const int z = flz_upto<NR>(LX, p);
-    const int t = p - z;
-    if (t > 0) { cov += t; set_range<NR>(V, p - t, p - 1); }
-  }
-  for (;;) {
-    const int e = ffz_from<NR>(R, p);      // run p..e
-    cov += K + (e - p);
-    set_range<NR>(V, p, e);
-    const int b = e + K;
-    if (b > last) break;
-    p = ffs_stride3<NR>(H, b);
-    if (p < 0) break;
-  }
-  return cov;
-}
-
-// highest set bit at a position i <= from with (from - i) % 3 == 0, or -1
-template <int NR> __device__ __forceinline__ int fls_stride3_down(const Mask<NR>& m, int from) {
-  const uint64_t PAT = 0x9249249249249249ull;
-#pragma unroll
-  for (int wi = NR - 1; wi >= 0; --wi) {
-    const int base = wi * 64;
-    if (from >= base) {
-      uint64_t v = m.w[wi];
-      const int res = ((from % 3) - (wi % 3) + 3) % 3;
-      v &= PAT << res;
-      if (from < base + 63) v &= (2ull << (from - base)) - 1;
-      if (v) return base + 63 - __builtin_clzll(v);
-    }
-  }
-  return -1;
-}
-
-// SPEC §3 for the REVERSE-COMPLEMENT strand, evaluated directly on masks indexed by read position i (rc position
-// j = P-1-i): the walk advances towards lower i, "left" is towards higher i. Same arithmetic as walk_masks on the
-// bit-reversed masks, without reversing them. H/R/LX are the rc strand's facts at read position i.
-template <int NR>
-__device__ __forceinline__ int walk_masks_down(const Mask<NR>& H, const Mask<NR>& R, const Mask<NR>& LX, int L, int K, Mask<NR>& V) {
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) V.w[wi] = 0;
-  const int last = L - K;                       // = P-1
-  int ip = fls_stride3_down<NR>(H, last);       // rc position 0 is read position last
-  if (ip < 0) return 0;
-  int cov = 0;
-  const int pj = last - ip;
-  if (pj >= L / 5 && pj > 0) {                  // left extension: consecutive LX bits going UP from ip
-    const int z = ffz_from<NR>(LX, ip);
-    const int t = z - ip;
-    if (t > 0) { cov += t; set_range<NR>(V, ip + 1, ip + t); }
-  }
-  for (;;) {
-    const int ei = flz_upto<NR>(R, ip);         // run ip .. ei (downwards)
-    cov += K + (ip - ei);
-    set_range<NR>(V, ei, ip);
-    const int bj = (last - ei) + K;
-    if (bj > last) break;
-    ip = fls_stride3_down<NR>(H, last - bj);
-    if (ip < 0) break;
-  }
-  return cov;
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // per-lane facts of one k-mer position for both strands
 struct PosFacts {
   uint32_t payF, payR;   // payload for the read strand / for the reverse-complement strand (PAY_ABSENT if none)
@@ -320,12 +100,11 @@ template <int NR> struct Strand {
 // wave AND-reduction folds them. Typical reads (all classes inside one locus) need ONE memory round trip here (the
 // descriptors) instead of the seed-row + per-word gather of a dense-row layout. Prefetching the descriptors before the
 // walk was tried and lost (112 VGPRs -> 4 waves/SIMD, 18.8 ms vs 17.8 ms). acc[t] (lane l) = word l + 64 t. Returns |eq|.
-struct DescRegs { uint32_t w0, nw, off; uint64_t m0, m1; };
+struct DescRegs { uint32_t w0, nw; uint64_t m; };   // ColDesc in registers (nb_internal.h): nw == 1 -> m is the word, else the index of the span in `packed`
 
 __device__ __forceinline__ DescRegs load_desc(const DevIndex& ix, uint32_t colour) {
-  const uint4* p = reinterpret_cast<const uint4*>(&ix.desc[colour]);
-  const uint4 a = p[0], b = p[1];
-  DescRegs d; d.w0 = a.x; d.nw = a.y; d.off = a.z; d.m0 = ((uint64_t)b.y << 32) | b.x; d.m1 = ((uint64_t)b.w << 32) | b.z;
+  const uint4 a = *reinterpret_cast<const uint4*>(&ix.desc[colour]);
+  DescRegs d; d.w0 = a.x; d.nw = a.y; d.m = ((uint64_t)a.w << 32) | a.z;
   return d;
 }
 // bit `lane` of a wave-UNIFORM 64-bit mask as a per-lane boolean: the mask's SGPR pair is used as the lane mask of a
@@ -348,13 +127,13 @@ __device__ __forceinline__ uint32_t intersect_descs(const DevIndex& ix, const St
 #pragma unroll
   for (int t = 0; t < TW; ++t) acc[t] = 0ull;
   uint32_t n = 0;
-  for (uint32_t j = lo; j < hi; ++j) {            // wave-uniform; usually one or two words
+  for (uint32_t j = lo; j < hi; ++j) {            // wave-uniform; one word for components of <= 64 sequences
     uint64_t v = ~0ull; bool need = false;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { const uint32_t idx = j - d[r].w0; need |= idx >= 2u; v &= idx == 0u ? d[r].m0 : (idx == 1u ? d[r].m1 : ~0ull); }
-    if (__ballot(need)) {                          // some class is wider than its two inline words here
+    for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { if (d[r].nw == 1u) v &= d[r].m; else need = true; }   // (a one-word span inside the window IS word j)
+    if (__ballot(need)) {                          // some class is wider than one word here: its span lives in `packed`
 #pragma unroll
-      for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { const uint32_t idx = j - d[r].w0; if (idx >= 2u) v &= ix.packed[(size_t)d[r].off + idx]; }
+      for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r]) && d[r].nw != 1u) v &= ix.packed[(size_t)(uint32_t)d[r].m + (j - d[r].w0)];
     }
     v = wave_and_u64(v);
     n += (uint32_t)__popcll(v);
@@ -467,8 +246,7 @@ __device__ __forceinline__ int map_both_strands_fast(const DevIndex& ix, const u
     for (int r = 0; r < NR; ++r) {
       const uint32_t colour = lane_bit(H.w[r]) ? col[r] : 0u;
       const char* g = reinterpret_cast<const char*>(&ix.desc[colour]);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[2 * r][0], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16), (__attribute__((address_space(3))) void*)&lds[2 * r + 1][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[r][0], 16, 0, 0);
     }
   };
   {
@@ -747,8 +525,7 @@ __device__ __forceinline__ int tri_finish(const DevIndex& ix, const TriProbe<CT>
     for (int r = 0; r < 3; ++r) {
       const uint32_t colour = lane_bit(H.m[r]) ? col[r] : 0u;
       const char* g = reinterpret_cast<const char*>(&ix.desc[colour]);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[2 * r][0], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16), (__attribute__((address_space(3))) void*)&lds[2 * r + 1][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[r][0], 16, 0, 0);
     }
   };
   if (lds && anyF) { pre = 1; fetch_descs(HF, F.col); }
@@ -825,9 +602,13 @@ __device__ __forceinline__ uint32_t intern_class(const DevClasses& ct, int W, in
           if (lane == 0) { atomicOr(ct.err, 1u); __hip_atomic_store(&ct.ids[h], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
           return NB_NO_CLASS;
         }
+        uint32_t wlo = 0xFFFFu, whi = 0u;
 #pragma unroll
         for (int t = 0; t < TW; ++t) { const int w = lane + 64 * t;
-          if (w < W) __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          if (w < W) __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (acc[t]) { wlo = (uint32_t)w < wlo ? (uint32_t)w : wlo; whi = (uint32_t)w > whi ? (uint32_t)w : whi; } }
+        wlo = wave_min_u32(wlo); whi = wave_max_u32(whi);
+        if (lane == 0) __hip_atomic_store(&ct.spans[id], wlo | (whi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&ct.ids[h], id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -855,14 +636,6 @@ __device__ __forceinline__ uint32_t intern_class(const DevClasses& ct, int W, in
   return NB_NO_CLASS;
 }
 
-// SPEC §4 checks 1-2 on a mapped strand (cheap part): returns 0 if it may be valid, else the reason.
-__device__ __forceinline__ int cheap_reason_p(int cov, int pmin, const BatchArgs& a) {
-  if (cov == 0) return NB_NO_HIT;
-  if (cov < a.score_threshold) return NB_SCORE_THRESHOLD;
-  if (cov < pmin) return NB_SCORE_PERCENT;
-  return 0;
-}
-__device__ __forceinline__ int cheap_reason(int cov, int L, const BatchArgs& a) { return cheap_reason_p(cov, (int)a.pct_min[L], a); }
 
 // ------------------------------------------------------------------------------------------------------------
 // single-end kernel: one read per wave, grid-stride over the batch.
@@ -873,21 +646,22 @@ template <int NR, int TW, bool TRI, bool CT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ctv, const DevClasses* __restrict__ ctp, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   constexpr bool LDS_DESC = TW == 1 && (TRI || NR == 2);   // (wide class rows go through `packed` anyway: a loss on c5; one round of positions: neutral)
-  __shared__ uint4 s_desc[LDS_DESC ? 4 : 1][LDS_DESC ? 2 * NR : 1][LDS_DESC ? 64 : 1];   // per wave: 3 residues x 2 halves of a 32-byte descriptor per lane
+  __shared__ uint4 s_desc[LDS_DESC ? 4 : 1][LDS_DESC ? NR : 1][LDS_DESC ? 64 : 1];   // per wave: one 16-byte descriptor per lane and residue / round
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
   const long long r0 = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  const long long n_items = a.n_dev ? (long long)*a.n_dev : a.n;   // (redo list of the lane-per-read path: the count lives on the device)
   TriRec nxt{}; int Lnxt = 0;
   if constexpr (TRI) {
-    if (r0 < a.n) {
+    if (r0 < n_items) {
       Lnxt = a.lens ? (int)a.lens[r0] : a.max_len; if (Lnxt > a.max_len) Lnxt = a.max_len;
       if (Lnxt >= ix.K) nxt = tri_load_record(reads_ro + (size_t)r0 * a.stride, a.nwb, Lnxt, ix.K, lane);
     }
   }
-  for (long long r = r0; r < a.n; r += nwaves) {
+  for (long long r = r0; r < n_items; r += nwaves) {
     int L;
     TriRec rec{};
     if constexpr (TRI) {
@@ -900,7 +674,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
     int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0; uint32_t cls = NB_NO_CLASS; int covF = 0, covR = 0;
     auto prefetch_next = [&]() {
       const long long rn = r + nwaves;
-      if (rn < a.n) {
+      if (rn < n_items) {
         Lnxt = a.lens ? (int)a.lens[rn] : a.max_len; if (Lnxt > a.max_len) Lnxt = a.max_len;
         if (Lnxt >= ix.K) nxt = tri_load_record(reads_ro + (size_t)rn * a.stride, a.nwb, Lnxt, ix.K, lane);
       }
@@ -942,8 +716,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
               for (int rr = 0; rr < NR; ++rr) {
-                const uint4 da = s_desc[wave][2 * rr][lane], db = s_desc[wave][2 * rr + 1][lane];
-                d[rr].w0 = da.x; d[rr].nw = da.y; d[rr].off = da.z; d[rr].m0 = ((uint64_t)db.y << 32) | db.x; d[rr].m1 = ((uint64_t)db.w << 32) | db.z;
+                const uint4 da = s_desc[wave][rr][lane];
+                d[rr].w0 = da.x; d[rr].nw = da.y; d[rr].m = ((uint64_t)da.w << 32) | da.z;
               }
             }
             n = isR ? intersect_descs<NR, TW>(ix, SR, d, lane, acc) : intersect_descs<NR, TW>(ix, SF, d, lane, acc);
@@ -1246,26 +1020,7 @@ __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevC
 thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
-#define NB_HIP(call)                                                                                     \
-  do {                                                                                                   \
-    hipError_t e_ = (call);                                                                              \
-    if (e_ != hipSuccess) { set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return NB_ERR_HIP; } \
-  } while (0)
-
 }  // namespace nb
-
-struct nb_index { nb::HostIndex* h; };
-
-struct nb_ctx {
-  int device = 0;
-  int n_cu = 256;
-  // bound index (device copies)
-  nb::Bucket* d_slots = nullptr; nb::CBucket* d_ctable = nullptr; bool compact = false; nb::CHash chash{}; nb::ColDesc* d_desc = nullptr; uint64_t* d_packed = nullptr; nb::KmerHash hash{}; int W = 0, K = 0, n_seqs = 0; int64_t index_bytes = 0;
-  // class table
-  nb::DevClasses ct{}; nb::DevClasses* d_ct = nullptr; int64_t max_classes = 0;   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
-  // score_percent table
-  uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0; std::vector<uint16_t> pct_host;
-};
 
 using namespace nb;
 
@@ -1308,6 +1063,8 @@ static int launch_se(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hipStrea
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL((nb_align_se_kernel<NR, TW, TRI, CT>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, (const DevClasses*)c->d_ct, a, a.reads);
   NB_HIP(hipGetLastError());
+  { char buf[96]; std::snprintf(buf, sizeof buf, "nb_align_se_kernel<%d, %d, %s, %s>", NR, TW, TRI ? "true" : "false", CT ? "true" : "false");
+    if (!c->last_kernels.empty()) c->last_kernels += ";"; c->last_kernels += buf; }
   return NB_OK;
 }
 
@@ -1319,6 +1076,7 @@ static int launch_general(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, hip
   const long long blocks = resident_blocks(c, nb_align_general_kernel<NR, TW, MODE, CT>, a.n);
   hipLaunchKernelGGL((nb_align_general_kernel<NR, TW, MODE, CT>), dim3((unsigned)blocks), dim3(256), 0, s, ix, c->ct, a);
   NB_HIP(hipGetLastError());
+  { char buf[96]; std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d, %d, %s>", NR, TW, MODE, CT ? "true" : "false"); c->last_kernels = buf; }
   return NB_OK;
 }
 
@@ -1370,7 +1128,7 @@ int32_t nb_ctx_create(int32_t device_id, int64_t max_classes, nb_ctx** out) {
   unsigned int cl = 10; while ((1ull << cl) < 2ull * (uint64_t)max_classes) ++cl; c->ct.cap_log2 = cl;
   const size_t cap = (size_t)1 << cl;
   NB_HIP(hipMalloc((void**)&c->ct.keys, cap * 8)); NB_HIP(hipMalloc((void**)&c->ct.ids, cap * 4));
-  NB_HIP(hipMalloc((void**)&c->ct.counts, (size_t)max_classes * 8));
+  NB_HIP(hipMalloc((void**)&c->ct.counts, (size_t)max_classes * 8)); NB_HIP(hipMalloc((void**)&c->ct.spans, (size_t)max_classes * 4));
   NB_HIP(hipMalloc((void**)&c->ct.n_classes, 4)); NB_HIP(hipMalloc((void**)&c->ct.err, 4));
   NB_HIP(hipMalloc((void**)&c->ct.reasons, NB_NUM_REASONS * 8));
   NB_HIP(hipMemset(c->ct.keys, 0, cap * 8)); NB_HIP(hipMemset(c->ct.ids, 0, cap * 4));
@@ -1384,7 +1142,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
 
@@ -1407,7 +1165,7 @@ int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
   const HostIndex& h = *ix->h;
   s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = h.compact ? (int64_t)h.ctable.size() * 2 : (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
   s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
-  s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0;
+  s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0; s->words_internal = h.words_dev;
   s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
   return NB_OK;
 }
@@ -1450,7 +1208,7 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   HostIndex& h = *ix->h;
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.rows);
   c->d_slots = nullptr; c->d_ctable = nullptr; c->d_desc = nullptr; c->d_packed = nullptr; c->ct.rows = nullptr;
-  c->compact = h.compact; c->chash = h.chash;
+  c->compact = h.compact; c->chash = h.chash; c->max_desc_nw = h.max_desc_nw;
   if (h.compact) {
     NB_HIP(hipMalloc((void**)&c->d_ctable, h.ctable.size() * sizeof(CBucket)));
     NB_HIP(hipMemcpy(c->d_ctable, h.ctable.data(), h.ctable.size() * sizeof(CBucket), hipMemcpyHostToDevice));
@@ -1461,10 +1219,10 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   if (!h.compact) NB_HIP(hipMemcpy(c->d_slots, h.buckets.data(), h.buckets.size() * sizeof(Bucket), hipMemcpyHostToDevice));
   NB_HIP(hipMemcpy(c->d_desc, h.desc.data(), h.desc.size() * sizeof(ColDesc), hipMemcpyHostToDevice));
   NB_HIP(hipMemcpy(c->d_packed, h.packed.data(), h.packed.size() * 8, hipMemcpyHostToDevice));
-  NB_HIP(hipMalloc((void**)&c->ct.rows, (size_t)c->max_classes * (size_t)h.words * 8));
+  NB_HIP(hipMalloc((void**)&c->ct.rows, (size_t)c->max_classes * (size_t)h.words_dev * 8));
   if (!c->d_ct) NB_HIP(hipMalloc((void**)&c->d_ct, sizeof(DevClasses)));
   NB_HIP(hipMemcpy(c->d_ct, &c->ct, sizeof(DevClasses), hipMemcpyHostToDevice));
-  c->hash = h.hash; c->W = h.words; c->K = h.k; c->n_seqs = h.n_seqs;
+  c->hash = h.hash; c->W = h.words_dev; c->W_ext = h.words; c->inv_perm = h.inv_perm; c->K = h.k; c->n_seqs = h.n_seqs;
   c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
 }
@@ -1503,7 +1261,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   const int lmax = max_len > mate_max_len ? max_len : mate_max_len;
   const int positions = lmax - c->K + 1;
   if (positions > NB_MAX_POSITIONS) { set_error("nb_align_batch: read longer than NB_MAX_POSITIONS + k - 1"); return NB_ERR_UNSUPPORTED; }
-  if (c->W > 64 * 4) { set_error("nb_align_batch: more than 16384 reference sequences"); return NB_ERR_UNSUPPORTED; }
+  if (c->W > 64 * 4) { set_error("nb_align_batch: the library needs more than 256 words per class row (about 16 000 sequences)"); return NB_ERR_UNSUPPORTED; }
   if (n == 0) return NB_OK;
   NB_HIP(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1518,6 +1276,36 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   a.discard_multiple = cfg->discard_multiple_matches; a.intersect_level = cfg->intersect_level;
   a.require_valid_pair = cfg->require_valid_pair; a.strand_filter = cfg->strand_filter;
   const int nr = positions < 1 ? 1 : (positions + 63) / 64;
+  c->last_kernels.clear();
+  // Lane-per-read path (nb_lane.hip): single-end, exact mode, compact table, every class inside one 64-bit word. Two launches map the
+  // batch (forward orientation, then the reads whose better strand is the reverse one); what the online walk cannot finish exactly is
+  // gathered and goes through the wave-per-read kernel below.
+  const char* lane_env = std::getenv("NB_LANE");
+  if (!d_mates && cfg->num_mismatches == 0 && c->compact && c->max_desc_nw == 1 && positions >= 1 && !(lane_env && lane_env[0] == '0')) {
+    const int64_t stride = a.stride;
+    if (c->lists_cap < n) {
+      (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;
+      NB_HIP(hipMalloc((void**)&c->d_lists, (size_t)n * 2 * 4)); NB_HIP(hipMalloc((void**)&c->d_redo_lens, (size_t)n * 2)); NB_HIP(hipMalloc((void**)&c->d_redo_out, (size_t)n * 16));
+      c->lists_cap = n;
+    }
+    if (c->redo_words_cap < n * stride) {
+      (void)hipFree(c->d_redo_reads); c->d_redo_reads = nullptr;
+      NB_HIP(hipMalloc((void**)&c->d_redo_reads, (size_t)(n * stride) * 8)); c->redo_words_cap = n * stride;
+    }
+    if (!c->d_list_counters) NB_HIP(hipMalloc((void**)&c->d_list_counters, 8));
+    LaneLists ll{c->d_lists, c->d_lists + c->lists_cap, c->d_list_counters};
+    rc = launch_lane(c, nr, ix, a, ll, s); if (rc != NB_OK) return rc;
+    { char buf[96]; std::snprintf(buf, sizeof buf, "nb_lane_kernel<%d, 0>;nb_lane_kernel<%d, 1>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr); c->last_kernels = buf; }
+    rc = launch_lane_gather(c, a, ll, c->d_redo_reads, c->d_redo_lens, s); if (rc != NB_OK) return rc;
+    BatchArgs b = a;
+    b.reads = c->d_redo_reads; b.lens = a.lens ? c->d_redo_lens : nullptr; b.n_dev = c->d_list_counters + 1;
+    b.out_class = a.out_class ? c->d_redo_out : nullptr; b.out_info = a.out_info ? c->d_redo_out + c->lists_cap : nullptr;
+    b.out_cov = a.out_cov ? reinterpret_cast<uint64_t*>(c->d_redo_out + 2 * c->lists_cap) : nullptr;
+    rc = (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, b, s) : dispatch_se<4, true>(c, nr, positions, ix, b, s);
+    if (rc != NB_OK) return rc;
+    BatchArgs sc = a; sc.n = c->lists_cap;
+    return launch_lane_scatter(c, sc, ll, c->d_redo_out, s);
+  }
   if (d_mates || cfg->num_mismatches > 0)   // pairs and tolerated mismatches take the general (eager, LDS-staged) kernel
   {
     const bool exact = cfg->num_mismatches == 0;
@@ -1538,11 +1326,34 @@ int32_t nb_classes_count(nb_ctx* c, int64_t* n) {
   *n = (int64_t)v; return NB_OK;
 }
 
+// rows of the class table are kept in INTERNAL sequence numbering on the device (nb_internal.h, ColDesc); callers get bitsets over the
+// ORIGINAL sequence indices, words_per_row = ceil(n_seqs / 64) words per row
+static int read_rows_external(nb_ctx* c, int64_t first, int64_t count, uint64_t* rows) {
+  std::vector<uint64_t> tmp((size_t)count * (size_t)c->W);
+  NB_HIP(hipMemcpy(tmp.data(), c->ct.rows + (size_t)first * (size_t)c->W, tmp.size() * 8, hipMemcpyDeviceToHost));
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, std::min<int64_t>((int64_t)std::thread::hardware_concurrency(), count * (int64_t)c->W / (1 << 18))));
+  auto work = [&](int64_t lo, int64_t hi) {
+    std::memset(rows + (size_t)lo * (size_t)c->W_ext, 0, (size_t)(hi - lo) * (size_t)c->W_ext * 8);
+    for (int64_t r = lo; r < hi; ++r) {
+      const uint64_t* in = tmp.data() + (size_t)r * (size_t)c->W; uint64_t* out = rows + (size_t)r * (size_t)c->W_ext;
+      for (int w = 0; w < c->W; ++w) for (uint64_t v = in[w]; v; v &= v - 1) {
+          const int32_t o = c->inv_perm[(size_t)w * 64 + (size_t)__builtin_ctzll(v)];
+          if (o >= 0) out[o >> 6] |= 1ull << (o & 63);
+        }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work, count * t / T, count * (t + 1) / T);
+  work(0, count / T);
+  for (auto& x : th) x.join();
+  return NB_OK;
+}
+
 int32_t nb_classes_read(nb_ctx* c, int64_t cap, uint64_t* rows, int64_t* counts) {
   int64_t n = 0; const int rc = nb_classes_count(c, &n); if (rc != NB_OK) return rc;
   if (cap < n) { set_error("nb_classes_read: cap smaller than the number of classes"); return NB_ERR_INVALID; }
   if (n == 0) return NB_OK;
-  if (rows) NB_HIP(hipMemcpy(rows, c->ct.rows, (size_t)n * (size_t)c->W * 8, hipMemcpyDeviceToHost));
+  if (rows) { const int r2 = read_rows_external(c, 0, n, rows); if (r2 != NB_OK) return r2; }
   if (counts) NB_HIP(hipMemcpy(counts, c->ct.counts, (size_t)n * 8, hipMemcpyDeviceToHost));
   return NB_OK;
 }
@@ -1551,7 +1362,7 @@ int32_t nb_classes_read_range(nb_ctx* c, int64_t first, int64_t count, uint64_t*
   int64_t n = 0; const int rc = nb_classes_count(c, &n); if (rc != NB_OK) return rc;
   if (first < 0 || count < 0 || first + count > n) { set_error("nb_classes_read_range: range outside the known classes"); return NB_ERR_INVALID; }
   if (count == 0) return NB_OK;
-  if (rows) NB_HIP(hipMemcpy(rows, c->ct.rows + (size_t)first * (size_t)c->W, (size_t)count * (size_t)c->W * 8, hipMemcpyDeviceToHost));
+  if (rows) { const int r2 = read_rows_external(c, first, count, rows); if (r2 != NB_OK) return r2; }
   if (counts) NB_HIP(hipMemcpy(counts, c->ct.counts + first, (size_t)count * 8, hipMemcpyDeviceToHost));
   return NB_OK;
 }
@@ -1628,10 +1439,12 @@ int32_t nb_copy_d2h_async(nb_ctx* c, void* dst, const void* d_src, int64_t bytes
   return NB_OK;
 }
 
+const char* nb_last_kernel_names(nb_ctx* c) { return c ? c->last_kernels.c_str() : ""; }
+
 const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t paired) {
   static thread_local char buf[96];
   const int positions = max_len - k + 1; const int nr = positions < 1 ? 1 : (positions + 63) / 64; const int W = (n_seqs + 63) / 64;
-  const char* ct = (k <= COMPACT_MAX_K && !(std::getenv("NB_TABLE") && std::string(std::getenv("NB_TABLE")) == "wide")) ? "true" : "false";   // compact table (nb_internal.h)
+  const char* ct = (k <= COMPACT_MAX_K && !(std::getenv("NB_TABLE") && std::string(std::getenv("NB_TABLE")) == "wide") && n_seqs <= 2000) ? "true" : "false";   // (a guess from the shape: the real choice is by table size, nb_index.cpp; nb_last_kernel_names(ctx) is exact)
   if (paired) std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d, %d, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? 2 : 1, ct);
   else std::snprintf(buf, sizeof buf, "nb_align_se_kernel<%d, %d, %s, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? "true" : "false", ct);
   return buf;

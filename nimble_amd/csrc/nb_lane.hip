@@ -1,0 +1,338 @@
+// nb_lane.hip — the lane-per-read kernels: 64 reads per wave, one read per lane (single-end, exact mode, compact table, classes of one
+// 64-bit word — i.e. every BASELINE library up to the L2-resident table sizes; everything else stays with nb_kernels.hip).
+//
+// Why: the wave-per-read kernel spends ~1 100 wave-instructions per read, 470 of them scalar (mask walk, control) with 64 lanes
+// waiting, and uses 131 of 192 lane slots of a 150-bp read. Here a wave issues ~130 vector instructions per k-mer POSITION for 64
+// reads at once (~250 per read), the walk of docs/SPEC.md §3 runs ONLINE per lane as the positions stream by, and no lane idles.
+//
+//   stream    every lane stages its packed record in LDS (transposed, conflict-free) and rolls its k-mer and the reverse
+//             complement forward one base per step (2-bit shift-in; N bases reset a run-length counter);
+//   lookup    canonical k-mer -> compact_probe -> both candidate buckets of the (2,2) cuckoo table (nb_internal.h), four positions in
+//             flight per lane, then the 16-byte colour descriptor of the hit (renumbered sequences: one word per class);
+//   walk      the identity R[i] = LX[i+1] (the (K+1)-mer that makes k-mer i right-extendable by the next base is the one that makes
+//             k-mer i+1 left-extendable by the previous base) lets every fact of position i be computed from the bases seen so far,
+//             so seed scan (stride 3), runs, re-seeding and the running AND of the visited classes advance in lock-step with the
+//             stream; the opposite strand's hit / extension bits are collected as per-lane masks and walked once at the end
+//             (coverage only);
+//   decide    SPEC §4 per lane. A read whose better strand is the opposite one goes on a worklist (wave ballot + prefix count: hit
+//             compaction) and is mapped by a second launch in reverse-complement orientation; reads the online walk cannot finish
+//             exactly here (a non-empty left extension, both strands viable) go on the redo list of the wave-per-read kernel;
+//   intern    per lane, lock-free, in the same class table as nb_kernels.hip: one state-machine step per loop iteration for every
+//             lane (no lane ever spins inside the loop on a slot another lane of ITS OWN wave is still publishing).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+
+#include "nb_device.h"
+
+namespace nb {
+
+// per-lane interning of a one-word set {word index lo, bits a0} in the shared class table; returns the class id or NB_NO_CLASS.
+// Same table protocol as intern_class (nb_kernels.hip): key = content hash, full-content verification through (spans, word).
+__device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, bool want, uint32_t lo, uint64_t a0) {
+  const uint64_t hx = mix64(a0 ^ (0x9E3779B97F4A7C15ull * (uint64_t)(lo + 1u)));
+  const uint64_t key = hx ? hx : 1ull;
+  const uint64_t smask = (1ull << ct.cap_log2) - 1;
+  uint64_t h = (key * HASH_MULT) >> (64 - ct.cap_log2);
+  uint32_t result = NB_NO_CLASS;
+  uint64_t probes = 0;                              // slots passed: the table is full once every slot was seen (intern_class has the same bound)
+  bool pending = want;
+  for (uint32_t it = 0; it < (1u << 24) && __ballot(pending); ++it) {
+    if (pending) {
+      const uint64_t cur = __hip_atomic_load(&ct.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == 0) {
+        unsigned long long expected = 0ull;
+        __hip_atomic_compare_exchange_strong(&ct.keys[h], &expected, (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (expected == 0ull) {                       // this lane owns the slot: allocate, write the row, publish
+          const uint32_t id = __hip_atomic_fetch_add(ct.n_classes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (id >= ct.max_classes) {
+            atomicOr(ct.err, 1u);
+            __hip_atomic_store(&ct.ids[h], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending = false;
+          } else {
+            for (int w = 0; w < W; ++w)
+              __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)((uint32_t)w == lo ? a0 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ct.spans[id], lo | (lo << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&ct.ids[h], id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            result = id; pending = false;
+          }
+        }
+        // lost the race: look at the same slot again in the next iteration (its key is set now)
+      } else if (cur == key) {
+        const uint32_t idp = __hip_atomic_load(&ct.ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (idp == 0xFFFFFFFFu) pending = false;      // table overflow recorded by the owner
+        else if (idp != 0u) {
+          const uint32_t id = idp - 1u;
+          const uint32_t sp = __hip_atomic_load(&ct.spans[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t word = __hip_atomic_load(&ct.rows[(size_t)id * W + lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (sp == (lo | (lo << 16)) && word == a0) { result = id; pending = false; }
+          else { h = (h + 1) & smask; ++probes; }     // a different set with the same 64-bit hash: keep probing
+        }
+        // idp == 0: the owner is still publishing: poll again in the next iteration
+      } else { h = (h + 1) & smask; ++probes; }
+      if (probes > smask) { atomicOr(ct.err, 1u); pending = false; }
+    }
+  }
+  if (pending) atomicOr(ct.err, 2u);
+  return result;
+}
+
+// highest set bit at a position i <= from with (from - i) % 3 == 0 etc. come from nb_device.h (Mask<NR>, walk_masks_down): they are
+// plain arithmetic on 64-bit words and work per lane as they do per wave.
+
+template <int NR, int PASS>
+__global__ __launch_bounds__(256) void nb_lane_kernel(DevIndex ix, DevClasses ct, BatchArgs a, LaneLists ll) {
+  constexpr int NWB = 2 * NR + 1, NWN = NR + 1, REC_DW = 2 * (NWB + NWN);
+  __shared__ uint32_t s_rec[4][REC_DW][64];     // per wave: dword j of lane l's record at [j][l] (bank = l mod 32: conflict-free)
+  __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const int K = ix.K;
+  const uint64_t kmask = (1ull << (2 * K)) - 1;
+  const int top = 2 * (K - 1);
+  const long long count = PASS == 0 ? a.n : (long long)ll.counters[0];
+  const int nwb = a.nwb, nwn = (a.nwb + 1) >> 1;
+  const int Pmax = a.max_len - K + 1;           // k-mer positions of the longest read of the batch
+  uint32_t (*rec)[64] = s_rec[wave];
+
+  for (long long base = ((long long)blockIdx.x * (blockDim.x >> 6) + wave) * 64; base < count; base += nwaves * 64) {
+    const long long idx = base + lane;
+    const bool active = idx < count;
+    const uint32_t r = active ? (PASS == 0 ? (uint32_t)idx : ll.rc_list[idx]) : 0u;
+    int L = 0;
+    if (active) { L = a.lens ? (int)a.lens[r] : a.max_len; if (L > a.max_len) L = a.max_len; }
+    // ---- stage the record (this lane's column of LDS) ----
+    {
+      const uint64_t* __restrict__ rp = a.reads + (size_t)r * a.stride;
+      for (int j = 0; j < nwb + nwn; ++j) {
+        const uint64_t w = active ? rp[j] : 0ull;
+        rec[2 * j][lane] = (uint32_t)w; rec[2 * j + 1][lane] = (uint32_t)(w >> 32);
+      }
+    }
+    const int last = L - K;
+    // ---- stream state ----
+    uint64_t fw = 0, rv = 0;
+    int nvalid = 0;
+    uint32_t prevb = 0;
+    auto advance = [&](int t) {                 // consume stream base t; afterwards fw / rv = the k-mer ending at base t and its reverse complement
+      const int j = PASS == 0 ? t : (L - 1 - t);
+      const bool in = t < L;
+      const int jj = in ? j : 0;
+      const uint32_t bw = rec[jj >> 4][lane], nw = rec[2 * nwb + (jj >> 5)][lane];
+      uint32_t b = (bw >> ((jj & 15) * 2)) & 3u;
+      const bool isn = (nw >> (jj & 31)) & 1u;
+      if (PASS == 1) b = 3u - b;
+      prevb = (uint32_t)fw & 3u;                // first base of the k-mer that ended at t - 1 = the base before the new k-mer
+      fw = (fw >> 2) | ((uint64_t)b << top);
+      rv = ((rv << 2) | (uint64_t)(3u - b)) & kmask;
+      nvalid = (in && !isn) ? nvalid + 1 : 0;
+    };
+    for (int t = 0; t < K - 1; ++t) advance(t);
+
+    // ---- online walk of the stream strand (docs/SPEC.md §3) ----
+    int mode = 0, cnt = 0, cov = 0, cl = 0;     // mode 0 = seeking a seed, 1 = inside a run, 2 = done; cl = consecutive LX bits ending here
+    bool seeded = false, started = false, slow = false;
+    uint32_t lo = 0; uint64_t a0 = 0;
+    Mask<NR> HO, RO;                            // opposite strand (PASS 0 only): hit bits, right-extension bits (rR of nb_kernels.hip)
+#pragma unroll
+    for (int wi = 0; wi < NR; ++wi) { HO.w[wi] = 0; RO.w[wi] = 0; }
+
+#pragma unroll
+    for (int wi = 0; wi < NR; ++wi) {
+      uint64_t curH = 0, curR = 0;
+      for (int q = 0; q < 64 && wi * 64 + q < Pmax; q += 4) {
+        uint32_t want[4], b1[4], b2[4], meta[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = wi * 64 + q + u;
+          advance(p + K - 1);
+          const bool valid = nvalid >= K;
+          const bool o = fw > rv;
+          const uint64_t c = o ? rv : fw;
+          const CProbe pr = compact_probe(c, ix.chash);
+          want[u] = pr.want; b1[u] = valid ? pr.b1 : 0u; b2[u] = valid ? pr.b2 : 0u;
+          meta[u] = (valid ? 1u : 0u) | (o ? 2u : 0u) | (nvalid >= K + 1 ? 4u : 0u) | (prevb << 3);
+        }
+        uint4 e1[4], e2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { e1[u] = load_cbucket(ix.ctable, b1[u]); e2[u] = load_cbucket(ix.ctable, b2[u]); }
+        uint32_t payS[4], payO[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) compact_match(e1[u], e2[u], want[u], (meta[u] >> 1) & 1u, meta[u] & 1u, payS[u], payO[u]);
+        // colour descriptors of the stream-strand hits (all of them while the walk is not over: nearly every hit is visited)
+        uint4 dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          dd[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (payS[u] != PAY_ABSENT && mode != 2) dd[u] = *reinterpret_cast<const uint4*>(&ix.desc[payS[u] >> 10]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = wi * 64 + q + u;
+          const bool prev_ok = meta[u] & 4u;
+          const uint32_t pb = (meta[u] >> 3) & 3u;
+          const bool hS = payS[u] != PAY_ABSENT;
+          const bool lxS = hS && prev_ok && ((payS[u] >> (4u + pb)) & 1u);
+          if (PASS == 0) {
+            const bool hO = payO[u] != PAY_ABSENT;
+            const bool rrO = hO && prev_ok && ((payO[u] >> (3u - pb)) & 1u);
+            curH |= (uint64_t)(hO ? 1u : 0u) << (q + u);
+            curR |= (uint64_t)(rrO ? 1u : 0u) << (q + u);
+          }
+          // one step of the walk at position p
+          bool visit = false;
+          if (mode == 1) {
+            if (lxS) { cov += 1; visit = true; }
+            else { mode = (p + K - 1 > last) ? 2 : 0; cnt = K - 1; }
+          }
+          cl = lxS ? cl + 1 : 0;
+          if (mode == 0 && cnt == 0 && hS) {
+            if (!seeded && p >= L / 5 && p > 0 && cl > 0) { cov += cl; slow = true; }   // left extension (SPEC §3): its length is exact here (coverage,
+            seeded = true; mode = 1; cov += K; visit = true;                        // cheap checks); its classes are not in the running AND, so a
+          }                                                                         // read that must be EVALUATED on this strand goes to the redo list
+          if (mode == 0) cnt = (cnt == 0) ? 2 : cnt - 1;
+          if (visit) {
+            const uint64_t m = ((uint64_t)dd[u].w << 32) | dd[u].z;
+            if (dd[u].y != 1u) slow = true;                             // a class wider than one word
+            if (!started) { lo = dd[u].x; a0 = m; started = true; }
+            else a0 = (dd[u].x == lo) ? (a0 & m) : 0ull;
+          }
+        }
+      }
+      HO.w[wi] = curH; RO.w[wi] = curR;
+    }
+
+    // ---- opposite strand: coverage from the masks (PASS 0), decision, output ----
+    const int pmin = a.lens ? (int)a.pct_min[L] : a.pct_fixed;
+    int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0;
+    uint32_t cls = NB_NO_CLASS;
+    bool to_rc = false, to_redo = false, final_ = false, call = false;
+    const bool isR = PASS == 1;
+    if (active && L >= K) {
+      int covO = 0, cheapO = NB_NO_HIT;
+      if (PASS == 0) {
+        Mask<NR> LO, V;                          // LX of the opposite strand at i = its R at i + 1 (header)
+#pragma unroll
+        for (int wi = 0; wi < NR; ++wi) LO.w[wi] = (RO.w[wi] >> 1) | (wi + 1 < NR ? (RO.w[wi + 1] << 63) : 0ull);
+        covO = any_set<NR>(HO) ? walk_masks_down<NR>(HO, RO, LO, L, K, V) : 0;
+        cheapO = cheap_reason_p(covO, pmin, a);
+        if (a.out_cov) a.out_cov[r] = (uint64_t)(cov & 0xFFFF) | ((uint64_t)(covO & 0xFFFF) << 16);
+      }
+      const int cheapS = cheap_reason_p(cov, pmin, a);
+      if (PASS == 0 && cheapS != 0 && cheapO != 0) { final_ = true; reason = cheapS > cheapO ? cheapS : cheapO; }
+      else if (PASS == 0 && cheapS == 0 && cheapO == 0) to_redo = true;      // both strands viable: lazy two-candidate evaluation
+      else if (PASS == 0 && cheapS != 0) to_rc = true;                       // only the opposite strand can be called
+      else if (slow) to_redo = true;
+      else {                                                                  // evaluate the stream strand (F in pass 0, R in pass 1)
+        final_ = true;
+        const uint32_t n = (uint32_t)__popcll(a0);
+        int rs = 0;
+        if (PASS == 1 && cheapS != 0) rs = cheapS;                            // (cannot happen: pass 0 saw the same coverage)
+        else if (n == 0) rs = NB_EMPTY_EQCLASS;
+        else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
+        else if ((isR && a.strand_filter == NB_STRAND_FIVEPRIME) || (!isR && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
+        if (rs) reason = rs;
+        else { score = cov; orient = isR ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
+      }
+    } else if (active) final_ = true;                                         // shorter than k: TOO_SHORT
+    // class interning for the called lanes (every lane takes part in the loop, see intern_lane)
+    cls = intern_lane(ct, ix.W, call, lo, a0);
+    if (call && cls != NB_NO_CLASS) atomicAdd(&ct.counts[cls], 1ull);
+    if (active && final_) {
+      atomicAdd(&s_reason[reason], 1u);
+      if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
+      if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
+      if (PASS == 0 && a.out_cov && L < K) a.out_cov[r] = 0ull;
+    }
+    // worklists: wave ballot + prefix count, one atomic per wave and list
+    {
+      const uint64_t mrc = __ballot(to_rc), mredo = __ballot(to_redo);
+      if (mrc) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&ll.counters[0], (uint32_t)__popcll(mrc));
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        if (to_rc) ll.rc_list[b0 + (uint32_t)__popcll(mrc & ((1ull << lane) - 1))] = r;
+      }
+      if (mredo) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&ll.counters[1], (uint32_t)__popcll(mredo));
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        if (to_redo) ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+}
+
+template <int NR, int PASS>
+static int launch_lane_t(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
+  static thread_local int per_cu = 0;
+  if (!per_cu) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nb_lane_kernel<NR, PASS>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (per_cu > 8) per_cu = 8;
+  }
+  int pc = per_cu;
+  if (const char* e = std::getenv("NB_LANE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) pc = v; }
+  long long blocks = (long long)c->n_cu * pc;
+  const long long need = PASS == 0 ? (a.n + 255) / 256 : blocks;     // pass 1: the list length is only known on the device
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL((nb_lane_kernel<NR, PASS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, ix, c->ct, a, ll);
+  NB_HIP(hipGetLastError());
+  return NB_OK;
+}
+
+// Both passes of the lane-per-read path for one batch (the caller then runs the wave-per-read kernel over ll.redo_list).
+int launch_lane(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
+  NB_HIP(hipMemsetAsync(ll.counters, 0, 8, s));
+  int rc;
+  switch (nr) {
+    case 1: rc = launch_lane_t<1, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<1, 1>(c, ix, a, ll, s); break;
+    case 2: rc = launch_lane_t<2, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<2, 1>(c, ix, a, ll, s); break;
+    case 3: rc = launch_lane_t<3, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<3, 1>(c, ix, a, ll, s); break;
+    case 4: rc = launch_lane_t<4, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<4, 1>(c, ix, a, ll, s); break;
+    default: rc = launch_lane_t<5, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<5, 1>(c, ix, a, ll, s); break;
+  }
+  return rc;
+}
+
+// The redo reads are gathered into a dense buffer so that the wave-per-read kernel runs on them unchanged (its batch length then comes from
+// the device: BatchArgs::n_dev); its per-read results land in a dense array and are scattered back to the reads' own slots.
+__global__ __launch_bounds__(256) void nb_lane_gather_kernel(const uint64_t* __restrict__ reads, const uint16_t* __restrict__ lens, int stride, const uint32_t* __restrict__ list,
+                                                              const uint32_t* __restrict__ n_dev, uint64_t* __restrict__ out_reads, uint16_t* __restrict__ out_lens) {
+  const long long n = (long long)*n_dev, total = n * stride;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long t = i / stride; const int w = (int)(i - t * stride);
+    out_reads[i] = reads[(size_t)list[t] * stride + w];
+    if (w == 0 && lens) out_lens[t] = lens[list[t]];
+  }
+}
+__global__ __launch_bounds__(256) void nb_lane_scatter_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ tmp,
+                                                               long long cap, uint32_t* out_class, uint32_t* out_info, uint64_t* out_cov) {
+  const long long n = (long long)*n_dev;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const uint32_t r = list[i];
+    if (out_class) out_class[r] = tmp[i];
+    if (out_info) out_info[r] = tmp[cap + i];
+    if (out_cov) out_cov[r] = reinterpret_cast<const uint64_t*>(tmp + 2 * cap)[i];
+  }
+}
+
+int launch_lane_gather(nb_ctx* c, const BatchArgs& a, const LaneLists& ll, uint64_t* redo_reads, uint16_t* redo_lens, hipStream_t s) {
+  hipLaunchKernelGGL(nb_lane_gather_kernel, dim3((unsigned)(c->n_cu * 4)), dim3(256), 0, s, a.reads, a.lens, a.stride, ll.redo_list, ll.counters + 1, redo_reads, redo_lens);
+  NB_HIP(hipGetLastError());
+  return NB_OK;
+}
+int launch_lane_scatter(nb_ctx* c, const BatchArgs& a, const LaneLists& ll, const uint32_t* redo_out, hipStream_t s) {
+  hipLaunchKernelGGL(nb_lane_scatter_kernel, dim3((unsigned)(c->n_cu * 2)), dim3(256), 0, s, ll.redo_list, ll.counters + 1, redo_out, a.n, a.out_class, a.out_info, a.out_cov);
+  NB_HIP(hipGetLastError());
+  return NB_OK;
+}
+
+}  // namespace nb

@@ -152,6 +152,10 @@ class Context:
         check(_lib.lib().nb_align_batch(self._h, ct.byref(cfg), p(reads), p(lens), int(max_len), p(mates), p(mate_lens),
                                         int(mate_max_len), int(n), p(out_class), p(out_info), p(out_cov), sh))
 
+    def last_kernels(self):
+        """Names of the kernels the last align_batch launched (dominant first)."""
+        return (_lib.lib().nb_last_kernel_names(self._h) or b"").decode().split(";")
+
     def sync(self, stream=None):
         import torch
         if stream is None:

@@ -45,7 +45,7 @@ def test_c5_10k_seq_library_full_size(built):
     index = engine.Index(strs, 20)
     st = index.stats()
     assert st["words_per_row"] == 157 and st["n_kmers"] > 2_000_000
-    assert engine._lib.lib().nb_kernel_name(L, 20, len(strs), 0) == b"nb_align_se_kernel<3, 4, true, true>"
+    assert engine._lib.lib().nb_kernel_name(L, 20, len(strs), 0) == b"nb_align_se_kernel<3, 4, true, false>"
     d_reads, first = synth.synth_reads_packed_torch(seqs, n, L, 5, dev, return_codes_of_first=20000)
     res = check_fullsize_properties(index, strs, engine.make_config(), d_reads, first, L, max_classes=1 << 23)
     assert 0.5 < res["called_frac"] < 0.7            # (100 alleles per locus: more reads end with an empty intersection than on c2)
