@@ -71,6 +71,8 @@ typedef struct nb_index_stats_t {
   int64_t n_colours;      /* equivalence classes of the graph */
   int64_t words_per_row;  /* u64 words per colour bitset = ceil(n_seqs/64) */
   int64_t device_bytes;   /* bytes the index occupies in HBM once uploaded */
+  int64_t ph_table_bytes; /* perfect-hash table of the lane-per-read kernels (16-byte entries; 0 = not built) and its first level,  */
+  int64_t ph_pilot_bytes; /* one byte per group, which the kernels stage in LDS (csrc/nb_internal.h, PHEntry)                    */
   int32_t k;
   int32_t uploaded;
   int32_t compact;        /* 1: compact cuckoo table (csrc/nb_internal.h), 0: wide table */

@@ -31,7 +31,7 @@ class NbConfig(ct.Structure):
 class NbIndexStats(ct.Structure):
     _fields_ = [
         ("n_seqs", ct.c_int64), ("n_kmers", ct.c_int64), ("n_canonical", ct.c_int64), ("table_slots", ct.c_int64), ("table_bytes", ct.c_int64),
-        ("n_colours", ct.c_int64), ("words_per_row", ct.c_int64), ("device_bytes", ct.c_int64),
+        ("n_colours", ct.c_int64), ("words_per_row", ct.c_int64), ("device_bytes", ct.c_int64), ("ph_table_bytes", ct.c_int64), ("ph_pilot_bytes", ct.c_int64),
         ("k", ct.c_int32), ("uploaded", ct.c_int32), ("compact", ct.c_int32), ("words_internal", ct.c_int32),
     ]
 

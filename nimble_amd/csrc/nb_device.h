@@ -264,6 +264,7 @@ struct nb_ctx;
 namespace nb {
 // nb_lane.hip: both lane-per-read passes of one batch, then gather of the redo reads; nb_lane_scatter puts their results back
 int launch_lane(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
+int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block);   // 0 = the lane path does not fit this shape
 int launch_lane_gather(nb_ctx* c, const BatchArgs& a, const LaneLists& ll, uint64_t* redo_reads, uint16_t* redo_lens, hipStream_t s);
 int launch_lane_scatter(nb_ctx* c, const BatchArgs& a, const LaneLists& ll, const uint32_t* redo_out, hipStream_t s);
 }  // namespace nb
@@ -281,6 +282,8 @@ struct nb_ctx {
   // worklists of the lane-per-read path (nb_lane.hip): reads to map in reverse-complement orientation, reads for the wave-per-read kernel
   uint32_t* d_lists = nullptr; int64_t lists_cap = 0; uint32_t* d_list_counters = nullptr; int max_desc_nw = 0;
   uint64_t* d_redo_reads = nullptr; int64_t redo_words_cap = 0; uint16_t* d_redo_lens = nullptr; uint32_t* d_redo_out = nullptr;   // gathered redo reads + their results (4 u32 per read)
+  void* d_lane_tail = nullptr;     // LaneTail of the current batch (nb_lane.hip)
+  nb::PHEntry* d_ph_table = nullptr; uint8_t* d_ph_pilots = nullptr; nb::PHash ph{}; bool has_ph = false;   // perfect-hash table of the lane kernels
   std::string last_kernels;        // kernels launched by the last nb_align_batch (nb_last_kernel_names)   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
   // score_percent table
   uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0; std::vector<uint16_t> pct_host;

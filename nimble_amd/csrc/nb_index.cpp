@@ -303,6 +303,71 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     }
     if (!done) { delete ix; set_error("nb_index_build: could not place the k-mers in the compact table"); return NB_ERR_UNSUPPORTED; }
     ix->hash = KmerHash{0, 0, 0};
+
+    // 5b. perfect-hash table of the lane-per-read kernels (nb_internal.h): hash and displace, one-byte pilots, groups keyed by rem
+    const char* ph_env = std::getenv("NB_PH");
+    if (ix->max_desc_nw == 1 && !(ph_env && ph_env[0] == '0')) {
+      const int64_t n = n_canon;
+      // groups: as many as the LDS budget of the first level allows, but not more than one per 2.5 k-mers (smaller groups fill the
+      // table higher: a group of s k-mers finds a free pilot among 256 only while (1 - fill)^s stays above a few per cent)
+      int64_t pilot_cap = PH_MAX_PILOT_BYTES;
+      if (const char* e = std::getenv("NB_PH_PILOT_KB")) { const int64_t v = std::atoll(e); if (v >= 1 && v <= 150) pilot_cap = v << 10; }
+      const int64_t G = std::max<int64_t>(1, std::min<int64_t>(pilot_cap, (int64_t)((double)n / 2.5)));
+      const double lambda = (double)n / (double)G;
+      for (double alpha = 0.95; alpha >= 0.55 && !ix->has_ph; alpha -= 0.02) {
+        const uint64_t N = std::max<uint64_t>({(uint64_t)((double)n / alpha) + 1, nb_min, 1024});
+        if ((int64_t)N * 16 > PH_MAX_TABLE_BYTES || N > 0x7FFFFFFFull || lambda > 16.0) break;
+        PHash h{}; h.a = ix->chash.a; h.c = ix->chash.c; h.n_slots = (uint32_t)N; h.n_groups = (uint32_t)G; h.hb = hb; h.himask = ix->chash.himask; h.stride = (uint32_t)(N >> (hb + 2));
+        std::vector<PHProbe> pr((size_t)n);
+        std::vector<uint32_t> gcount((size_t)G + 1, 0);
+        for (int64_t i = 0; i < n; ++i) { pr[(size_t)i] = ph_probe(canons[(size_t)i].key, h); ++gcount[pr[(size_t)i].group + 1]; }
+        std::vector<uint32_t> gstart(gcount);
+        for (int64_t g = 0; g < G; ++g) gstart[(size_t)g + 1] += gstart[(size_t)g];
+        std::vector<uint32_t> members((size_t)n), fill(gstart.begin(), gstart.end() - 1);
+        for (int64_t i = 0; i < n; ++i) members[fill[pr[(size_t)i].group]++] = (uint32_t)i;
+        std::vector<uint32_t> order((size_t)G); std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+          const uint32_t sx = gstart[x + 1] - gstart[x], sy = gstart[y + 1] - gstart[y]; return sx != sy ? sx > sy : x < y; });
+        std::vector<uint8_t> used((size_t)N, 0), pilots((size_t)G, 0);
+        std::vector<uint32_t> slots;
+        bool ok = true;
+        for (uint32_t g : order) {
+          const uint32_t b = gstart[g], e = gstart[g + 1];
+          if (b == e) continue;
+          bool placed = false;
+          for (uint32_t pilot = 0; pilot < 256 && !placed; ++pilot) {
+            slots.clear(); bool clash = false;
+            for (uint32_t t = b; t < e && !clash; ++t) {
+              const uint32_t sl = ph_slot(pr[members[t]], pilot, h);
+              if (used[sl]) clash = true;
+              for (uint32_t x : slots) if (x == sl) clash = true;
+              slots.push_back(sl);
+            }
+            if (clash) continue;
+            for (uint32_t x : slots) used[x] = 1;
+            pilots[g] = (uint8_t)pilot; placed = true;
+          }
+          if (!placed) { ok = false; break; }
+        }
+        if (!ok) continue;
+        std::vector<PHEntry> tab((size_t)N, PHEntry{0xFFFFFFFFu, PAY_ABSENT, 0ull});
+        bool bad_key = false;
+        for (int64_t i = 0; i < n; ++i) {
+          const Canon& cn = canons[(size_t)i]; const PHProbe& q = pr[(size_t)i];
+          const bool both = cn.pay[0] != PAY_ABSENT && cn.pay[1] != PAY_ABSENT;
+          const int strand = cn.pay[0] != PAY_ABSENT ? 0 : 1;
+          const uint32_t pay = cn.pay[strand], colour = pay >> 10;
+          const ColDesc& d = ix->desc[colour];
+          PHEntry en; en.key = q.want | (both ? 2u : 0u) | (uint32_t)strand;
+          en.pay = (pay & 0x3FFu) | (d.nw == 1 ? (d.w0 << 11) : ((1u << 10) | (colour << 11)));
+          en.m = d.nw == 1 ? d.m : 0ull;
+          if (en.key == 0xFFFFFFFFu || d.w0 > 0x1FFFFFu || colour > 0x1FFFFFu) bad_key = true;
+          tab[ph_slot(q, pilots[q.group], h)] = en;
+        }
+        if (bad_key) break;
+        ix->has_ph = true; ix->ph = h; ix->ph_table.swap(tab); ix->ph_pilots.swap(pilots);
+      }
+    }
   } else {
   uint64_t nb64 = (uint64_t)((double)n_canon / (SLOTS_PER_BUCKET * TABLE_MAX_LOAD)) + 1;
   if (nb64 < 256) nb64 = 256;

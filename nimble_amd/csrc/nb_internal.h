@@ -108,6 +108,39 @@ NB_HD inline CProbe compact_probe(uint64_t canon, const CHash& h) {
   return p;
 }
 
+// ---- PERFECT-HASH table of the lane-per-read kernels (nb_lane.hip): ONE 16-byte entry per lookup, first level in LDS -------------------
+// Measured on MI355X (profiles/r02_gather_microbench.jsonl, r02_tuning_notes.md): the chip serves ~266 G random requests/s from an
+// L2-resident table whatever the request width (8 / 16 B alike) — the lane-per-read kernel with the cuckoo table (2 buckets + 1 colour
+// descriptor per position = 353 requests per 150-bp read) sits at 94 % of that. Fewer requests per position is the only lever: this table
+// answers a lookup with a single dwordx4 that carries the payload AND the class word, i.e. 131 requests per read.
+//   (t, rem) = the same bijective split of the canonical k-mer as the compact table (rem = 30 bits, t = the other hb + 2 bits);
+//   group = mulhi(rem * GM, n_groups): a function of rem alone; pilot[group] (one byte, the table's first level: staged in LDS by every
+//   workgroup); slot = (mulhi((rem ^ pilot * PM) * GM2, n_slots) + t * stride) mod n_slots, stride = n_slots >> (hb + 2). "Hash and
+//   displace": the builder picks each group's pilot so that all its k-mers land on free slots. Exactness without stored k-mers: an
+//   entry with the queried rem belongs to the queried group and was hashed with the same pilot; two k-mers with equal rem differ in
+//   t, i.e. by a non-zero multiple of stride below n_slots: same (slot, rem) = same k-mer — absent k-mers can never match.
+//   entry {key, pay, m}: key = rem << 2 | both << 1 | strand (strand as in the compact table; both = the k-mer occurs on both strands:
+//   rare, the read is handed to the wave-per-read kernel); pay = rext:4 lext:4 r_int l_int | wide << 10 | (wide ? colour : w0) << 11;
+//   m = the class word (internal numbering) when !wide. Empty slot: key = 0xFFFFFFFF.
+struct PHEntry { uint32_t key, pay; uint64_t m; };
+static_assert(sizeof(PHEntry) == 16, "perfect-hash entry must be 16 bytes");
+struct PHash { uint32_t a, c, n_slots, n_groups, hb, himask, stride; };
+constexpr uint32_t PH_GM = 0x9E3779B1u, PH_PM = 0x85EBCA6Bu, PH_GM2 = 0xC2B2AE35u;
+constexpr int64_t PH_MAX_PILOT_BYTES = 80 << 10;        // first level must fit LDS next to the per-wave record staging
+constexpr int64_t PH_MAX_TABLE_BYTES = 12ll << 20;      // beyond that the second level leaves the L2s: the wave-per-read kernels take over
+struct PHProbe { uint32_t want, toff, group; };         // toff = t * stride
+NB_HD inline PHProbe ph_probe(uint64_t canon, const PHash& h) {
+  const uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
+  const uint32_t m = (lo * h.a) ^ (hi * h.c);
+  const uint32_t hi2 = hi ^ ((m >> 7) & h.himask);
+  PHProbe p; p.want = m << 2; p.toff = ((hi2 << 2) | (m >> 30)) * h.stride; p.group = nb_mulhi32((m & 0x3FFFFFFFu) * PH_GM, h.n_groups);
+  return p;
+}
+NB_HD inline uint32_t ph_slot(const PHProbe& p, uint32_t pilot, const PHash& h) {
+  const uint32_t s = nb_mulhi32(((p.want >> 2) ^ (pilot * PH_PM)) * PH_GM2, h.n_slots) + p.toff;     // both terms < n_slots
+  return s >= h.n_slots ? s - h.n_slots : s;
+}
+
 // A colour (equivalence class of the graph) on the device, 16 bytes, one dwordx4. Bit positions are INTERNAL sequence numbers: the
 // index builder renumbers the sequences so that every connected component of the "share a k-mer" relation (a locus, for a
 // gene-family library) starts at a 64-bit word boundary or lies inside one word (nb_index.cpp, step 3a). A class is a subset of one
@@ -143,6 +176,10 @@ struct HostIndex {
   int n_seqs = 0;
   int words = 0;                      // u64 words per colour row in ORIGINAL numbering = ceil(n_seqs / 64): eq_rows, the C-ABI
   int words_dev = 0;                  // u64 words per row in INTERNAL numbering (device descriptors, class table rows)
+  bool has_ph = false;                // perfect-hash table of the lane-per-read kernels (built next to the compact table when it fits)
+  PHash ph{};
+  std::vector<PHEntry> ph_table;      // ph.n_slots entries
+  std::vector<uint8_t> ph_pilots;     // ph.n_groups bytes
   int max_desc_nw = 1;                // widest class span in words (1 = every class inside one word: the lane-per-read kernels apply)
   std::vector<int32_t> perm;          // original sequence index -> internal bit position
   std::vector<int32_t> inv_perm;      // internal bit position -> original sequence index, -1 = padding

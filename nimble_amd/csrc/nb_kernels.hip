@@ -1142,7 +1142,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_lane_tail); (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
 
@@ -1165,8 +1165,8 @@ int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
   const HostIndex& h = *ix->h;
   s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = h.compact ? (int64_t)h.ctable.size() * 2 : (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
   s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
-  s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0; s->words_internal = h.words_dev;
-  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
+  s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0; s->words_internal = h.words_dev; s->ph_table_bytes = (int64_t)(h.ph_table.size() * sizeof(PHEntry)); s->ph_pilot_bytes = (int64_t)h.ph_pilots.size();
+  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size()); s->k = h.k; s->uploaded = h.uploaded;
   return NB_OK;
 }
 
@@ -1209,6 +1209,12 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.rows);
   c->d_slots = nullptr; c->d_ctable = nullptr; c->d_desc = nullptr; c->d_packed = nullptr; c->ct.rows = nullptr;
   c->compact = h.compact; c->chash = h.chash; c->max_desc_nw = h.max_desc_nw;
+  (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); c->d_ph_table = nullptr; c->d_ph_pilots = nullptr; c->has_ph = h.has_ph; c->ph = h.ph;
+  if (h.has_ph) {
+    NB_HIP(hipMalloc((void**)&c->d_ph_table, h.ph_table.size() * sizeof(PHEntry))); NB_HIP(hipMalloc((void**)&c->d_ph_pilots, h.ph_pilots.size()));
+    NB_HIP(hipMemcpy(c->d_ph_table, h.ph_table.data(), h.ph_table.size() * sizeof(PHEntry), hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(c->d_ph_pilots, h.ph_pilots.data(), h.ph_pilots.size(), hipMemcpyHostToDevice));
+  }
   if (h.compact) {
     NB_HIP(hipMalloc((void**)&c->d_ctable, h.ctable.size() * sizeof(CBucket)));
     NB_HIP(hipMemcpy(c->d_ctable, h.ctable.data(), h.ctable.size() * sizeof(CBucket), hipMemcpyHostToDevice));
@@ -1223,7 +1229,7 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   if (!c->d_ct) NB_HIP(hipMalloc((void**)&c->d_ct, sizeof(DevClasses)));
   NB_HIP(hipMemcpy(c->d_ct, &c->ct, sizeof(DevClasses), hipMemcpyHostToDevice));
   c->hash = h.hash; c->W = h.words_dev; c->W_ext = h.words; c->inv_perm = h.inv_perm; c->K = h.k; c->n_seqs = h.n_seqs;
-  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8); h.uploaded = 1;
+  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size()); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
 }
 
@@ -1281,7 +1287,8 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   // batch (forward orientation, then the reads whose better strand is the reverse one); what the online walk cannot finish exactly is
   // gathered and goes through the wave-per-read kernel below.
   const char* lane_env = std::getenv("NB_LANE");
-  if (!d_mates && cfg->num_mismatches == 0 && c->compact && c->max_desc_nw == 1 && positions >= 1 && !(lane_env && lane_env[0] == '0')) {
+  int lane_wpb = 0;
+  if (!d_mates && cfg->num_mismatches == 0 && c->has_ph && positions >= 1 && !(lane_env && lane_env[0] == '0') && lane_lds_bytes(c, max_len, &lane_wpb) > 0) {
     const int64_t stride = a.stride;
     if (c->lists_cap < n) {
       (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;

@@ -83,51 +83,103 @@ __device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, boo
 // highest set bit at a position i <= from with (from - i) % 3 == 0 etc. come from nb_device.h (Mask<NR>, walk_masks_down): they are
 // plain arithmetic on 64-bit words and work per lane as they do per wave.
 
+// What the main loop needs, by value (SGPRs); everything the tail of a batch needs (class table, outputs, filters, lists) is read from
+// device memory at the point of use (LaneTail): kernel arguments that stay live across the position loop would spill.
+struct LaneHead {
+  const PHEntry* table; const uint8_t* pilots; PHash ph; int K;
+  const uint64_t* reads; const uint16_t* lens; int max_len, stride, nwb;
+  long long n;
+  const uint32_t* list; const uint32_t* list_n;      // pass 1: reads (bit 31 = map in reverse-complement orientation) and their count
+  int pilot_lds_bytes, rec_dwords;                   // dynamic LDS: [pilots][per wave: rec_dwords x 64 dwords]
+};
+struct LaneTail { DevClasses ct; BatchArgs a; LaneLists ll; int W; };
+
+constexpr int LANE_MAX_WAVES = 16;
+
+// one lookup in the perfect-hash table (nb_internal.h): pilot from LDS, ONE dwordx4 from the table
+__device__ __forceinline__ uint32_t ph_lookup_slot(const LaneHead& h, const uint8_t* s_pilots, const PHProbe& pr) {
+  return ph_slot(pr, (uint32_t)s_pilots[pr.group], h.ph);
+}
+
+// PASS 0: every read of the batch, orientation chosen per lane by three probes (start, middle, end of the read): the strand that hits
+// is streamed, the other one is only recorded as masks. PASS 1: the reads of the worklist, in the orientation the list entry names.
 template <int NR, int PASS>
-__global__ __launch_bounds__(256) void nb_lane_kernel(DevIndex ix, DevClasses ct, BatchArgs a, LaneLists ll) {
-  constexpr int NWB = 2 * NR + 1, NWN = NR + 1, REC_DW = 2 * (NWB + NWN);
-  __shared__ uint32_t s_rec[4][REC_DW][64];     // per wave: dword j of lane l's record at [j][l] (bank = l mod 32: conflict-free)
+__global__ __launch_bounds__(1024) void nb_lane_kernel(LaneHead h, const LaneTail* __restrict__ tp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
-  if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
-  __syncthreads();
+  uint8_t* s_pilots = s_dyn;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  const int K = ix.K;
+  const int wpb = (int)(blockDim.x >> 6);
+  uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;   // dword j of this lane's record at rec[j * 64 + lane]
+  if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)      // first level of the table -> LDS (16 bytes per thread and step)
+    *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
+  __syncthreads();
+  const long long nwaves = (long long)gridDim.x * wpb;
+  const int K = h.K;
   const uint64_t kmask = (1ull << (2 * K)) - 1;
   const int top = 2 * (K - 1);
-  const long long count = PASS == 0 ? a.n : (long long)ll.counters[0];
-  const int nwb = a.nwb, nwn = (a.nwb + 1) >> 1;
-  const int Pmax = a.max_len - K + 1;           // k-mer positions of the longest read of the batch
-  uint32_t (*rec)[64] = s_rec[wave];
+  const long long count = PASS == 0 ? h.n : (long long)*h.list_n;
+  const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1;
+  const int Pmax = h.max_len - K + 1;           // k-mer positions of the longest read of the batch
 
-  for (long long base = ((long long)blockIdx.x * (blockDim.x >> 6) + wave) * 64; base < count; base += nwaves * 64) {
+  for (long long base = ((long long)blockIdx.x * wpb + wave) * 64; base < count; base += nwaves * 64) {
     const long long idx = base + lane;
     const bool active = idx < count;
-    const uint32_t r = active ? (PASS == 0 ? (uint32_t)idx : ll.rc_list[idx]) : 0u;
+    uint32_t r = 0; bool rcf = false;            // read index; stream = reverse complement of the read
+    if (active) { if (PASS == 0) r = (uint32_t)idx; else { const uint32_t e = h.list[idx]; r = e & 0x7FFFFFFFu; rcf = (e >> 31) != 0; } }
     int L = 0;
-    if (active) { L = a.lens ? (int)a.lens[r] : a.max_len; if (L > a.max_len) L = a.max_len; }
+    if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
     // ---- stage the record (this lane's column of LDS) ----
     {
-      const uint64_t* __restrict__ rp = a.reads + (size_t)r * a.stride;
+      const uint64_t* __restrict__ rp = h.reads + (size_t)r * h.stride;
       for (int j = 0; j < nwb + nwn; ++j) {
         const uint64_t w = active ? rp[j] : 0ull;
-        rec[2 * j][lane] = (uint32_t)w; rec[2 * j + 1][lane] = (uint32_t)(w >> 32);
+        rec[(2 * j) * 64 + lane] = (uint32_t)w; rec[(2 * j + 1) * 64 + lane] = (uint32_t)(w >> 32);
       }
+      rec[(2 * (nwb + nwn)) * 64 + lane] = 0u; rec[(2 * (nwb + nwn) + 1) * 64 + lane] = 0u;
     }
     const int last = L - K;
+    bool hard = false;                           // a k-mer that occurs on both strands was met: the wave-per-read kernel maps this read
+    // ---- orientation (PASS 0): which strand do the k-mers at the start, the middle and the end of the read hit? ----
+    if (PASS == 0 && last >= 0) {
+      int votes = 0;
+      uint4 pe[3]; uint32_t pw[3], pm[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int p = u == 0 ? 0 : (u == 1 ? last >> 1 : last);
+        const int j0 = p >> 4, sh = (p & 15) * 2;
+        const uint64_t lo64 = ((uint64_t)rec[(j0 + 1) * 64 + lane] << 32) | rec[j0 * 64 + lane];
+        const uint64_t hi64 = rec[(j0 + 2) * 64 + lane];
+        const uint64_t x = (sh ? ((lo64 >> sh) | (hi64 << (64 - sh))) : lo64) & kmask;
+        const int n0 = 2 * nwb + (p >> 5), nsh = p & 31;
+        const uint64_t nm = (((uint64_t)rec[(n0 + 1) * 64 + lane] << 32) | rec[n0 * 64 + lane]) >> nsh;
+        const bool valid = (nm & ((1ull << K) - 1)) == 0;
+        const uint64_t y = rc_kmer(x, K);
+        const bool o = x > y;
+        const PHProbe pr = ph_probe(o ? y : x, h.ph);
+        pw[u] = pr.want; pm[u] = (valid ? 1u : 0u) | (o ? 2u : 0u);
+        pe[u] = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_lookup_slot(h, s_pilots, pr) : 0u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const uint32_t d = pe[u].x ^ pw[u];
+        if ((pm[u] & 1u) && d < 4u && !(d & 2u)) votes += ((d & 1u) == ((pm[u] >> 1) & 1u)) ? 1 : -1;
+      }
+      rcf = votes < 0;
+    }
     // ---- stream state ----
     uint64_t fw = 0, rv = 0;
     int nvalid = 0;
     uint32_t prevb = 0;
     auto advance = [&](int t) {                 // consume stream base t; afterwards fw / rv = the k-mer ending at base t and its reverse complement
-      const int j = PASS == 0 ? t : (L - 1 - t);
       const bool in = t < L;
-      const int jj = in ? j : 0;
-      const uint32_t bw = rec[jj >> 4][lane], nw = rec[2 * nwb + (jj >> 5)][lane];
+      const int jj = in ? (rcf ? L - 1 - t : t) : 0;
+      const uint32_t bw = rec[(jj >> 4) * 64 + lane], nw = rec[(2 * nwb + (jj >> 5)) * 64 + lane];
       uint32_t b = (bw >> ((jj & 15) * 2)) & 3u;
       const bool isn = (nw >> (jj & 31)) & 1u;
-      if (PASS == 1) b = 3u - b;
+      b = rcf ? 3u - b : b;
       prevb = (uint32_t)fw & 3u;                // first base of the k-mer that ended at t - 1 = the base before the new k-mer
       fw = (fw >> 2) | ((uint64_t)b << top);
       rv = ((rv << 2) | (uint64_t)(3u - b)) & kmask;
@@ -143,49 +195,52 @@ __global__ __launch_bounds__(256) void nb_lane_kernel(DevIndex ix, DevClasses ct
 #pragma unroll
     for (int wi = 0; wi < NR; ++wi) { HO.w[wi] = 0; RO.w[wi] = 0; }
 
+    // software pipeline over blocks of four positions: the table loads of block n + 1 are in flight while block n's four walk steps run
+    uint32_t want[4], meta[4]; uint4 e[4];
+    auto probe_block = [&](int p0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        advance(p0 + u + K - 1);
+        const bool valid = nvalid >= K;
+        const bool o = fw > rv;
+        const PHProbe pr = ph_probe(o ? rv : fw, h.ph);
+        want[u] = pr.want;
+        meta[u] = (valid ? 1u : 0u) | (o ? 2u : 0u) | (nvalid >= K + 1 ? 4u : 0u) | (prevb << 3);
+        e[u] = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_lookup_slot(h, s_pilots, pr) : 0u]);
+      }
+    };
+    if (Pmax > 0) probe_block(0);
 #pragma unroll
     for (int wi = 0; wi < NR; ++wi) {
       uint64_t curH = 0, curR = 0;
       for (int q = 0; q < 64 && wi * 64 + q < Pmax; q += 4) {
-        uint32_t want[4], b1[4], b2[4], meta[4];
+        const int p0 = wi * 64 + q;
+        uint32_t cpay[4], cflag[4]; uint64_t cm[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int p = wi * 64 + q + u;
-          advance(p + K - 1);
-          const bool valid = nvalid >= K;
-          const bool o = fw > rv;
-          const uint64_t c = o ? rv : fw;
-          const CProbe pr = compact_probe(c, ix.chash);
-          want[u] = pr.want; b1[u] = valid ? pr.b1 : 0u; b2[u] = valid ? pr.b2 : 0u;
-          meta[u] = (valid ? 1u : 0u) | (o ? 2u : 0u) | (nvalid >= K + 1 ? 4u : 0u) | (prevb << 3);
+        for (int u = 0; u < 4; ++u) {          // decode the entries of this block: flags bit0 = stream-strand hit, bit1 = opposite-strand hit, bit2 = prev_ok
+          const uint32_t d = e[u].x ^ want[u];
+          const bool found = (meta[u] & 1u) && d < 4u;
+          const bool both = found && (d & 2u);
+          const bool isS = found && !both && ((d & 1u) == ((meta[u] >> 1) & 1u));
+          const bool isO = found && !both && !isS;
+          hard |= both;
+          cpay[u] = e[u].y; cm[u] = ((uint64_t)e[u].w << 32) | e[u].z;
+          cflag[u] = (isS ? 1u : 0u) | (isO ? 2u : 0u) | (meta[u] & 4u) | (meta[u] & 24u);
         }
-        uint4 e1[4], e2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { e1[u] = load_cbucket(ix.ctable, b1[u]); e2[u] = load_cbucket(ix.ctable, b2[u]); }
-        uint32_t payS[4], payO[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) compact_match(e1[u], e2[u], want[u], (meta[u] >> 1) & 1u, meta[u] & 1u, payS[u], payO[u]);
-        // colour descriptors of the stream-strand hits (all of them while the walk is not over: nearly every hit is visited)
-        uint4 dd[4];
+        if (p0 + 4 < Pmax) probe_block(p0 + 4);           // next block's lookups go out before this block's walk steps
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          dd[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (payS[u] != PAY_ABSENT && mode != 2) dd[u] = *reinterpret_cast<const uint4*>(&ix.desc[payS[u] >> 10]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int p = wi * 64 + q + u;
-          const bool prev_ok = meta[u] & 4u;
-          const uint32_t pb = (meta[u] >> 3) & 3u;
-          const bool hS = payS[u] != PAY_ABSENT;
-          const bool lxS = hS && prev_ok && ((payS[u] >> (4u + pb)) & 1u);
+          const int p = p0 + u;
+          const bool prev_ok = cflag[u] & 4u;
+          const uint32_t pb = (cflag[u] >> 3) & 3u;
+          const bool hS = cflag[u] & 1u;
+          const bool lxS = hS && prev_ok && ((cpay[u] >> (4u + pb)) & 1u);
           if (PASS == 0) {
-            const bool hO = payO[u] != PAY_ABSENT;
-            const bool rrO = hO && prev_ok && ((payO[u] >> (3u - pb)) & 1u);
+            const bool hO = cflag[u] & 2u;
+            const bool rrO = hO && prev_ok && ((cpay[u] >> (3u - pb)) & 1u);
             curH |= (uint64_t)(hO ? 1u : 0u) << (q + u);
             curR |= (uint64_t)(rrO ? 1u : 0u) << (q + u);
           }
-          // one step of the walk at position p
           bool visit = false;
           if (mode == 1) {
             if (lxS) { cov += 1; visit = true; }
@@ -198,22 +253,24 @@ __global__ __launch_bounds__(256) void nb_lane_kernel(DevIndex ix, DevClasses ct
           }                                                                         // read that must be EVALUATED on this strand goes to the redo list
           if (mode == 0) cnt = (cnt == 0) ? 2 : cnt - 1;
           if (visit) {
-            const uint64_t m = ((uint64_t)dd[u].w << 32) | dd[u].z;
-            if (dd[u].y != 1u) slow = true;                             // a class wider than one word
-            if (!started) { lo = dd[u].x; a0 = m; started = true; }
-            else a0 = (dd[u].x == lo) ? (a0 & m) : 0ull;
+            const uint32_t w0 = cpay[u] >> 11;
+            if (cpay[u] & (1u << 10)) slow = true;                      // a class wider than one word
+            if (!started) { lo = w0; a0 = cm[u]; started = true; }
+            else a0 = (w0 == lo) ? (a0 & cm[u]) : 0ull;
           }
         }
       }
       HO.w[wi] = curH; RO.w[wi] = curR;
     }
 
-    // ---- opposite strand: coverage from the masks (PASS 0), decision, output ----
+    // ---- tail: the other strand's coverage from its masks (PASS 0), SPEC §4 per lane, outputs, worklists ----
+    asm volatile("" ::: "memory");
+    const LaneTail& T = *tp;
+    const BatchArgs& a = T.a;
     const int pmin = a.lens ? (int)a.pct_min[L] : a.pct_fixed;
     int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0;
     uint32_t cls = NB_NO_CLASS;
-    bool to_rc = false, to_redo = false, final_ = false, call = false;
-    const bool isR = PASS == 1;
+    bool to_other = false, to_redo = false, final_ = false, call = false;
     if (active && L >= K) {
       int covO = 0, cheapO = NB_NO_HIT;
       if (PASS == 0) {
@@ -222,82 +279,101 @@ __global__ __launch_bounds__(256) void nb_lane_kernel(DevIndex ix, DevClasses ct
         for (int wi = 0; wi < NR; ++wi) LO.w[wi] = (RO.w[wi] >> 1) | (wi + 1 < NR ? (RO.w[wi + 1] << 63) : 0ull);
         covO = any_set<NR>(HO) ? walk_masks_down<NR>(HO, RO, LO, L, K, V) : 0;
         cheapO = cheap_reason_p(covO, pmin, a);
-        if (a.out_cov) a.out_cov[r] = (uint64_t)(cov & 0xFFFF) | ((uint64_t)(covO & 0xFFFF) << 16);
+        const int covF = rcf ? covO : cov, covR = rcf ? cov : covO;
+        if (a.out_cov) a.out_cov[r] = (uint64_t)(covF & 0xFFFF) | ((uint64_t)(covR & 0xFFFF) << 16);
       }
       const int cheapS = cheap_reason_p(cov, pmin, a);
-      if (PASS == 0 && cheapS != 0 && cheapO != 0) { final_ = true; reason = cheapS > cheapO ? cheapS : cheapO; }
+      if (hard) to_redo = true;
+      else if (PASS == 0 && cheapS != 0 && cheapO != 0) { final_ = true; reason = cheapS > cheapO ? cheapS : cheapO; }
       else if (PASS == 0 && cheapS == 0 && cheapO == 0) to_redo = true;      // both strands viable: lazy two-candidate evaluation
-      else if (PASS == 0 && cheapS != 0) to_rc = true;                       // only the opposite strand can be called
+      else if (PASS == 0 && cheapS != 0) to_other = true;                    // only the strand that was not streamed can be called
       else if (slow) to_redo = true;
-      else {                                                                  // evaluate the stream strand (F in pass 0, R in pass 1)
+      else {                                                                  // evaluate the stream strand
         final_ = true;
         const uint32_t n = (uint32_t)__popcll(a0);
         int rs = 0;
-        if (PASS == 1 && cheapS != 0) rs = cheapS;                            // (cannot happen: pass 0 saw the same coverage)
+        if (cheapS != 0) rs = cheapS;                                         // (pass 1 only, and then never: pass 0 saw the same coverage)
         else if (n == 0) rs = NB_EMPTY_EQCLASS;
         else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
-        else if ((isR && a.strand_filter == NB_STRAND_FIVEPRIME) || (!isR && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
+        else if ((rcf && a.strand_filter == NB_STRAND_FIVEPRIME) || (!rcf && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
         if (rs) reason = rs;
-        else { score = cov; orient = isR ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
+        else { score = cov; orient = rcf ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
       }
     } else if (active) final_ = true;                                         // shorter than k: TOO_SHORT
-    // class interning for the called lanes (every lane takes part in the loop, see intern_lane)
-    cls = intern_lane(ct, ix.W, call, lo, a0);
-    if (call && cls != NB_NO_CLASS) atomicAdd(&ct.counts[cls], 1ull);
+    cls = intern_lane(T.ct, T.W, call, lo, a0);                               // (every lane takes part in the loop, see intern_lane)
+    if (call && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], 1ull);
     if (active && final_) {
       atomicAdd(&s_reason[reason], 1u);
       if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
       if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
       if (PASS == 0 && a.out_cov && L < K) a.out_cov[r] = 0ull;
     }
-    // worklists: wave ballot + prefix count, one atomic per wave and list
-    {
-      const uint64_t mrc = __ballot(to_rc), mredo = __ballot(to_redo);
-      if (mrc) {
+    {   // worklists: wave ballot + prefix count, one atomic per wave and list
+      const uint64_t mo = __ballot(to_other), mredo = __ballot(to_redo);
+      if (mo) {
         uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&ll.counters[0], (uint32_t)__popcll(mrc));
+        if (lane == 0) b0 = atomicAdd(&T.ll.counters[0], (uint32_t)__popcll(mo));
         b0 = __builtin_amdgcn_readfirstlane(b0);
-        if (to_rc) ll.rc_list[b0 + (uint32_t)__popcll(mrc & ((1ull << lane) - 1))] = r;
+        if (to_other) T.ll.rc_list[b0 + (uint32_t)__popcll(mo & ((1ull << lane) - 1))] = r | (rcf ? 0u : 0x80000000u);
       }
       if (mredo) {
         uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&ll.counters[1], (uint32_t)__popcll(mredo));
+        if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
         b0 = __builtin_amdgcn_readfirstlane(b0);
-        if (to_redo) ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+        if (to_redo) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
       }
     }
   }
   __syncthreads();
-  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+}
+
+// dynamic LDS of one workgroup for reads up to max_len: first level of the table + record staging of `waves` waves; 0 if it cannot fit
+int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block) {
+  if (!c->has_ph) return 0;
+  const int nwb = (max_len + 31) / 32, nwn = (max_len + 63) / 64;
+  const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4, pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
+  const int64_t budget = (160 << 10) - 256;
+  int w = LANE_MAX_WAVES;
+  if (const char* e = std::getenv("NB_LANE_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= LANE_MAX_WAVES) w = v; }
+  while (w > 0 && pil + (int64_t)w * rec > budget) --w;
+  if (w < 4) return 0;                         // fewer than one wave per SIMD: not worth it
+  if (waves_per_block) *waves_per_block = w;
+  return pil + (int64_t)w * rec;
 }
 
 template <int NR, int PASS>
-static int launch_lane_t(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
-  static thread_local int per_cu = 0;
-  if (!per_cu) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nb_lane_kernel<NR, PASS>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-    if (per_cu > 8) per_cu = 8;
-  }
-  int pc = per_cu;
-  if (const char* e = std::getenv("NB_LANE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) pc = v; }
-  long long blocks = (long long)c->n_cu * pc;
-  const long long need = PASS == 0 ? (a.n + 255) / 256 : blocks;     // pass 1: the list length is only known on the device
+static int launch_lane_t(nb_ctx* c, const LaneHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
+  static thread_local bool attr_set = false;
+  if (!attr_set) { NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_lane_kernel<NR, PASS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
+  long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
+  const long long need = PASS == 0 ? (h.n + 64LL * waves - 1) / (64LL * waves) : blocks;     // pass 1: the list length is only known on the device
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL((nb_lane_kernel<NR, PASS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, ix, c->ct, a, ll);
+  hipLaunchKernelGGL((nb_lane_kernel<NR, PASS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
 
 // Both passes of the lane-per-read path for one batch (the caller then runs the wave-per-read kernel over ll.redo_list).
 int launch_lane(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
+  int waves = 0;
+  const int64_t lds = lane_lds_bytes(c, a.max_len, &waves);
+  if (lds <= 0) { set_error("launch_lane: shape does not fit"); return NB_ERR_UNSUPPORTED; }
   NB_HIP(hipMemsetAsync(ll.counters, 0, 8, s));
+  if (!c->d_lane_tail) NB_HIP(hipMalloc((void**)&c->d_lane_tail, sizeof(LaneTail)));
+  LaneTail t{c->ct, a, ll, ix.W};
+  NB_HIP(hipMemcpyAsync(c->d_lane_tail, &t, sizeof t, hipMemcpyHostToDevice, s));    // (pageable source: staged by the runtime before the call returns)
+  const int nwn = (a.nwb + 1) >> 1;
+  LaneHead h{c->d_ph_table, c->d_ph_pilots, c->ph, ix.K, a.reads, a.lens, a.max_len, a.stride, a.nwb, a.n, ll.rc_list, ll.counters,
+             (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16), 2 * (a.nwb + nwn) + 2};
+  const LaneTail* dt = (const LaneTail*)c->d_lane_tail;
   int rc;
   switch (nr) {
-    case 1: rc = launch_lane_t<1, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<1, 1>(c, ix, a, ll, s); break;
-    case 2: rc = launch_lane_t<2, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<2, 1>(c, ix, a, ll, s); break;
-    case 3: rc = launch_lane_t<3, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<3, 1>(c, ix, a, ll, s); break;
-    case 4: rc = launch_lane_t<4, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<4, 1>(c, ix, a, ll, s); break;
-    default: rc = launch_lane_t<5, 0>(c, ix, a, ll, s); if (rc == NB_OK) rc = launch_lane_t<5, 1>(c, ix, a, ll, s); break;
+    case 1: rc = launch_lane_t<1, 0>(c, h, dt, waves, lds, s); if (rc == NB_OK) rc = launch_lane_t<1, 1>(c, h, dt, waves, lds, s); break;
+    case 2: rc = launch_lane_t<2, 0>(c, h, dt, waves, lds, s); if (rc == NB_OK) rc = launch_lane_t<2, 1>(c, h, dt, waves, lds, s); break;
+    case 3: rc = launch_lane_t<3, 0>(c, h, dt, waves, lds, s); if (rc == NB_OK) rc = launch_lane_t<3, 1>(c, h, dt, waves, lds, s); break;
+    case 4: rc = launch_lane_t<4, 0>(c, h, dt, waves, lds, s); if (rc == NB_OK) rc = launch_lane_t<4, 1>(c, h, dt, waves, lds, s); break;
+    default: rc = launch_lane_t<5, 0>(c, h, dt, waves, lds, s); if (rc == NB_OK) rc = launch_lane_t<5, 1>(c, h, dt, waves, lds, s); break;
   }
   return rc;
 }
