@@ -332,7 +332,7 @@ def main():
                      "traffic_note": (f"bytes per launch, (FETCH_SIZE + WRITE_SIZE) KB from {traffic_src}: L2<->fabric requests (64 B per L2 miss; for scattered "
                                       "16..64-B gathers FETCH_SIZE was calibrated against a known request count, profiles/r02_fetch_calibration.txt: it counts "
                                       "64 B per missing request, no x2 correction applies); algorithmic bytes per launch = " + str(bytes_per_read * n)) if traffic else None,
-                     "kernel": engine._lib.lib().nb_kernel_name(L, args.k, len(strs), 0).decode(), "kernel_ms_avg": avg_kernel_s * 1e3,
+                     "kernel": ctx.last_kernels()[0], "kernels_per_step": ctx.last_kernels(), "kernel_ms_avg": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_read": bytes_per_read},
         # The nearest memory-side ceiling: the rate at which the chip serves RANDOM 16-byte gathers (one cuckoo bucket = one dwordx4 = one
         # L1->L2 request) from a table of this size, MEASURED by the standalone microbenchmark scripts/gather_bench.hip

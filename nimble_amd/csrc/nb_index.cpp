@@ -318,6 +318,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         const uint64_t N = std::max<uint64_t>({(uint64_t)((double)n / alpha) + 1, nb_min, 1024});
         if ((int64_t)N * 16 > PH_MAX_TABLE_BYTES || N > 0x7FFFFFFFull || lambda > 16.0) break;
         PHash h{}; h.a = ix->chash.a; h.c = ix->chash.c; h.n_slots = (uint32_t)N; h.n_groups = (uint32_t)G; h.hb = hb; h.himask = ix->chash.himask; h.stride = (uint32_t)(N >> (hb + 2));
+        if (h.stride >= (1u << 24) || hb + 2 > 16) break;                       // (24-bit multiply operands in ph_probe)
         std::vector<PHProbe> pr((size_t)n);
         std::vector<uint32_t> gcount((size_t)G + 1, 0);
         for (int64_t i = 0; i < n; ++i) { pr[(size_t)i] = ph_probe(canons[(size_t)i].key, h); ++gcount[pr[(size_t)i].group + 1]; }

@@ -114,7 +114,7 @@ NB_HD inline CProbe compact_probe(uint64_t canon, const CHash& h) {
 // descriptor per position = 353 requests per 150-bp read) sits at 94 % of that. Fewer requests per position is the only lever: this table
 // answers a lookup with a single dwordx4 that carries the payload AND the class word, i.e. 131 requests per read.
 //   (t, rem) = the same bijective split of the canonical k-mer as the compact table (rem = 30 bits, t = the other hb + 2 bits);
-//   group = mulhi(rem * GM, n_groups): a function of rem alone; pilot[group] (one byte, the table's first level: staged in LDS by every
+//   group = mulhi(rem << 2, n_groups): a function of rem alone; pilot[group] (one byte, the table's first level: staged in LDS by every
 //   workgroup); slot = (mulhi((rem ^ pilot * PM) * GM2, n_slots) + t * stride) mod n_slots, stride = n_slots >> (hb + 2). "Hash and
 //   displace": the builder picks each group's pilot so that all its k-mers land on free slots. Exactness without stored k-mers: an
 //   entry with the queried rem belongs to the queried group and was hashed with the same pilot; two k-mers with equal rem differ in
@@ -125,19 +125,21 @@ NB_HD inline CProbe compact_probe(uint64_t canon, const CHash& h) {
 struct PHEntry { uint32_t key, pay; uint64_t m; };
 static_assert(sizeof(PHEntry) == 16, "perfect-hash entry must be 16 bytes");
 struct PHash { uint32_t a, c, n_slots, n_groups, hb, himask, stride; };
-constexpr uint32_t PH_GM = 0x9E3779B1u, PH_PM = 0x85EBCA6Bu, PH_GM2 = 0xC2B2AE35u;
-constexpr int64_t PH_MAX_PILOT_BYTES = 80 << 10;        // first level must fit LDS next to the per-wave record staging
-constexpr int64_t PH_MAX_TABLE_BYTES = 12ll << 20;      // beyond that the second level leaves the L2s: the wave-per-read kernels take over
+constexpr uint32_t PH_PM = 0x9E3779u, PH_GM2 = 0xC2B2AE35u;   // PH_PM < 2^24: pilot * PH_PM is a full-rate 24-bit multiply
+constexpr int64_t PH_MAX_PILOT_BYTES = 96 << 10;        // first level must fit LDS next to the per-wave record staging (>= 8 waves per workgroup)
+constexpr int64_t PH_MAX_TABLE_BYTES = 16ll << 20;      // beyond that the second level leaves the L2s: the wave-per-read kernels take over
 struct PHProbe { uint32_t want, toff, group; };         // toff = t * stride
 NB_HD inline PHProbe ph_probe(uint64_t canon, const PHash& h) {
   const uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
-  const uint32_t m = (lo * h.a) ^ (hi * h.c);
+  const uint32_t m = (lo * h.a) ^ ((hi & 0xFFFFu) * (h.c & 0xFFFFFFu));          // (24-bit operands: v_mul_u32_u24)
   const uint32_t hi2 = hi ^ ((m >> 7) & h.himask);
-  PHProbe p; p.want = m << 2; p.toff = ((hi2 << 2) | (m >> 30)) * h.stride; p.group = nb_mulhi32((m & 0x3FFFFFFFu) * PH_GM, h.n_groups);
+  PHProbe p; p.want = m << 2;
+  p.toff = (((hi2 << 2) | (m >> 30)) & 0xFFFFu) * (h.stride & 0xFFFFFFu);          // t < 2^(hb + 2) <= 2^16, stride < 2^24
+  p.group = nb_mulhi32(p.want, h.n_groups);                                         // the top bits of rem: mixed by the multiply above
   return p;
 }
 NB_HD inline uint32_t ph_slot(const PHProbe& p, uint32_t pilot, const PHash& h) {
-  const uint32_t s = nb_mulhi32(((p.want >> 2) ^ (pilot * PH_PM)) * PH_GM2, h.n_slots) + p.toff;     // both terms < n_slots
+  const uint32_t s = nb_mulhi32(((p.want >> 2) ^ ((pilot & 0xFFu) * PH_PM)) * PH_GM2, h.n_slots) + p.toff;     // both terms < n_slots
   return s >= h.n_slots ? s - h.n_slots : s;
 }
 

@@ -94,7 +94,7 @@ struct LaneHead {
 };
 struct LaneTail { DevClasses ct; BatchArgs a; LaneLists ll; int W; };
 
-constexpr int LANE_MAX_WAVES = 16;
+constexpr int LANE_MAX_WAVES = 12;   // = the launch bound of nb_lane_kernel (768 threads: 3 waves per SIMD, up to 168 VGPRs)
 
 // one lookup in the perfect-hash table (nb_internal.h): pilot from LDS, ONE dwordx4 from the table
 __device__ __forceinline__ uint32_t ph_lookup_slot(const LaneHead& h, const uint8_t* s_pilots, const PHProbe& pr) {
@@ -104,7 +104,7 @@ __device__ __forceinline__ uint32_t ph_lookup_slot(const LaneHead& h, const uint
 // PASS 0: every read of the batch, orientation chosen per lane by three probes (start, middle, end of the read): the strand that hits
 // is streamed, the other one is only recorded as masks. PASS 1: the reads of the worklist, in the orientation the list entry names.
 template <int NR, int PASS>
-__global__ __launch_bounds__(1024) void nb_lane_kernel(LaneHead h, const LaneTail* __restrict__ tp) {
+__global__ __launch_bounds__(768) void nb_lane_kernel(LaneHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   uint8_t* s_pilots = s_dyn;
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(1024) void nb_lane_kernel(LaneHead h, const LaneTai
       rec[(2 * (nwb + nwn)) * 64 + lane] = 0u; rec[(2 * (nwb + nwn) + 1) * 64 + lane] = 0u;
     }
     const int last = L - K;
-    bool hard = false;                           // a k-mer that occurs on both strands was met: the wave-per-read kernel maps this read
+    uint32_t fl = 0;                             // per-lane flags kept in ONE VGPR (bools would live as 64-bit lane masks in SGPRs and spill):
+    constexpr uint32_t F_SEEDED = 1u, F_STARTED = 2u, F_SLOW = 4u, F_HARD = 8u;   // F_HARD: a k-mer on both strands was met (wave-per-read kernel maps the read)
     // ---- orientation (PASS 0): which strand do the k-mers at the start, the middle and the end of the read hit? ----
     if (PASS == 0 && last >= 0) {
       int votes = 0;
@@ -189,78 +190,83 @@ __global__ __launch_bounds__(1024) void nb_lane_kernel(LaneHead h, const LaneTai
 
     // ---- online walk of the stream strand (docs/SPEC.md §3) ----
     int mode = 0, cnt = 0, cov = 0, cl = 0;     // mode 0 = seeking a seed, 1 = inside a run, 2 = done; cl = consecutive LX bits ending here
-    bool seeded = false, started = false, slow = false;
     uint32_t lo = 0; uint64_t a0 = 0;
     Mask<NR> HO, RO;                            // opposite strand (PASS 0 only): hit bits, right-extension bits (rR of nb_kernels.hip)
 #pragma unroll
     for (int wi = 0; wi < NR; ++wi) { HO.w[wi] = 0; RO.w[wi] = 0; }
 
-    // software pipeline over blocks of four positions: the table loads of block n + 1 are in flight while block n's four walk steps run
-    uint32_t want[4], meta[4]; uint4 e[4];
-    auto probe_block = [&](int p0) {
+    // software pipeline over blocks of four positions, two register sets (A, B) used alternately: the table loads of the next block are
+    // in flight while the current block's four walk steps run; no copies between the sets. The walk step is branch-free (selects).
+    const int L5 = L / 5;
+    struct Blk { uint32_t want[4], meta[4]; uint4 e[4]; };
+    Blk A, B;
+    auto probe_block = [&](Blk& X, int p0) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         advance(p0 + u + K - 1);
         const bool valid = nvalid >= K;
         const bool o = fw > rv;
         const PHProbe pr = ph_probe(o ? rv : fw, h.ph);
-        want[u] = pr.want;
-        meta[u] = (valid ? 1u : 0u) | (o ? 2u : 0u) | (nvalid >= K + 1 ? 4u : 0u) | (prevb << 3);
-        e[u] = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_lookup_slot(h, s_pilots, pr) : 0u]);
+        X.want[u] = pr.want;
+        X.meta[u] = (valid ? 1u : 0u) | (o ? 2u : 0u) | (nvalid >= K + 1 ? 4u : 0u) | (prevb << 3);
+        X.e[u] = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_lookup_slot(h, s_pilots, pr) : 0u]);
       }
     };
-    if (Pmax > 0) probe_block(0);
+    uint64_t curH = 0, curR = 0;
+    auto walk_block = [&](const Blk& X, int p0, int q) {
 #pragma unroll
-    for (int wi = 0; wi < NR; ++wi) {
-      uint64_t curH = 0, curR = 0;
-      for (int q = 0; q < 64 && wi * 64 + q < Pmax; q += 4) {
-        const int p0 = wi * 64 + q;
-        uint32_t cpay[4], cflag[4]; uint64_t cm[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {          // decode the entries of this block: flags bit0 = stream-strand hit, bit1 = opposite-strand hit, bit2 = prev_ok
-          const uint32_t d = e[u].x ^ want[u];
-          const bool found = (meta[u] & 1u) && d < 4u;
-          const bool both = found && (d & 2u);
-          const bool isS = found && !both && ((d & 1u) == ((meta[u] >> 1) & 1u));
-          const bool isO = found && !both && !isS;
-          hard |= both;
-          cpay[u] = e[u].y; cm[u] = ((uint64_t)e[u].w << 32) | e[u].z;
-          cflag[u] = (isS ? 1u : 0u) | (isO ? 2u : 0u) | (meta[u] & 4u) | (meta[u] & 24u);
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u;
+        const uint32_t d = X.e[u].x ^ X.want[u], mt = X.meta[u], pay = X.e[u].y;
+        const bool found = (mt & 1u) && d < 4u;
+        const bool both = found && (d & 2u);
+        const bool hS = found && !both && ((d & 1u) == ((mt >> 1) & 1u));
+        const bool hO = found && !both && !hS;
+        fl |= both ? F_HARD : 0u;
+        const bool prev_ok = mt & 4u;
+        const uint32_t pb = (mt >> 3) & 3u;
+        const bool lxS = hS && prev_ok && ((pay >> (4u + pb)) & 1u);
+        if (PASS == 0) {
+          const bool rrO = hO && prev_ok && ((pay >> (3u - pb)) & 1u);
+          curH |= (uint64_t)(hO ? 1u : 0u) << (q + u);
+          curR |= (uint64_t)(rrO ? 1u : 0u) << (q + u);
         }
-        if (p0 + 4 < Pmax) probe_block(p0 + 4);           // next block's lookups go out before this block's walk steps
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int p = p0 + u;
-          const bool prev_ok = cflag[u] & 4u;
-          const uint32_t pb = (cflag[u] >> 3) & 3u;
-          const bool hS = cflag[u] & 1u;
-          const bool lxS = hS && prev_ok && ((cpay[u] >> (4u + pb)) & 1u);
-          if (PASS == 0) {
-            const bool hO = cflag[u] & 2u;
-            const bool rrO = hO && prev_ok && ((cpay[u] >> (3u - pb)) & 1u);
-            curH |= (uint64_t)(hO ? 1u : 0u) << (q + u);
-            curR |= (uint64_t)(rrO ? 1u : 0u) << (q + u);
-          }
-          bool visit = false;
-          if (mode == 1) {
-            if (lxS) { cov += 1; visit = true; }
-            else { mode = (p + K - 1 > last) ? 2 : 0; cnt = K - 1; }
-          }
-          cl = lxS ? cl + 1 : 0;
-          if (mode == 0 && cnt == 0 && hS) {
-            if (!seeded && p >= L / 5 && p > 0 && cl > 0) { cov += cl; slow = true; }   // left extension (SPEC §3): its length is exact here (coverage,
-            seeded = true; mode = 1; cov += K; visit = true;                        // cheap checks); its classes are not in the running AND, so a
-          }                                                                         // read that must be EVALUATED on this strand goes to the redo list
-          if (mode == 0) cnt = (cnt == 0) ? 2 : cnt - 1;
-          if (visit) {
-            const uint32_t w0 = cpay[u] >> 11;
-            if (cpay[u] & (1u << 10)) slow = true;                      // a class wider than one word
-            if (!started) { lo = w0; a0 = cm[u]; started = true; }
-            else a0 = (w0 == lo) ? (a0 & cm[u]) : 0ull;
-          }
+        // one step of SPEC §3 at position p, as selects
+        const bool is_run = mode == 1;
+        const bool cont = is_run && lxS, ended = is_run && !lxS;
+        mode = ended ? ((p + K - 1 > last) ? 2 : 0) : mode;
+        cnt = ended ? K - 1 : cnt;
+        cl = lxS ? cl + 1 : 0;
+        const bool seed = mode == 0 && cnt == 0 && hS;
+        const bool lext = seed && !(fl & F_SEEDED) && p >= L5 && p > 0 && cl > 0;   // left extension: its length is exact here (coverage, cheap
+        cov += (cont ? 1 : 0) + (seed ? K : 0) + (lext ? cl : 0);                   // checks); its classes are not in the running AND: such a read goes
+        mode = seed ? 1 : mode;                                                     // to the redo list if it has to be EVALUATED on this strand
+        cnt = mode == 0 ? (cnt == 0 ? 2 : cnt - 1) : cnt;
+        const bool visit = cont || seed;
+        const uint32_t w0 = pay >> 11;
+        const uint64_t m = ((uint64_t)X.e[u].w << 32) | X.e[u].z;
+        const bool first = visit && !(fl & F_STARTED);
+        const uint64_t anded = (w0 == lo) ? (a0 & m) : 0ull;
+        a0 = first ? m : (visit ? anded : a0);
+        lo = first ? w0 : lo;
+        fl |= (seed ? F_SEEDED : 0u) | (visit ? F_STARTED : 0u) | ((lext || (visit && (pay & (1u << 10)))) ? F_SLOW : 0u);   // (a class wider than one word: slow too)
+      }
+    };
+    if (Pmax > 0) probe_block(A, 0);
+#pragma unroll 1
+    for (int wi = 0; wi < NR; ++wi) {            // (not unrolled: 64 positions of straight-line code per mask word is enough for the instruction cache)
+      curH = 0; curR = 0;
+      for (int q = 0; q < 64 && wi * 64 + q < Pmax; q += 8) {
+        const int p0 = wi * 64 + q;
+        if (p0 + 4 < Pmax) probe_block(B, p0 + 4);
+        walk_block(A, p0, q);
+        if (p0 + 4 < Pmax) {
+          if (p0 + 8 < Pmax) probe_block(A, p0 + 8);
+          walk_block(B, p0 + 4, q + 4);
         }
       }
-      HO.w[wi] = curH; RO.w[wi] = curR;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) if (j == wi) { HO.w[j] = curH; RO.w[j] = curR; }
     }
 
     // ---- tail: the other strand's coverage from its masks (PASS 0), SPEC §4 per lane, outputs, worklists ----
@@ -283,11 +289,11 @@ __global__ __launch_bounds__(1024) void nb_lane_kernel(LaneHead h, const LaneTai
         if (a.out_cov) a.out_cov[r] = (uint64_t)(covF & 0xFFFF) | ((uint64_t)(covR & 0xFFFF) << 16);
       }
       const int cheapS = cheap_reason_p(cov, pmin, a);
-      if (hard) to_redo = true;
+      if (fl & F_HARD) to_redo = true;
       else if (PASS == 0 && cheapS != 0 && cheapO != 0) { final_ = true; reason = cheapS > cheapO ? cheapS : cheapO; }
       else if (PASS == 0 && cheapS == 0 && cheapO == 0) to_redo = true;      // both strands viable: lazy two-candidate evaluation
       else if (PASS == 0 && cheapS != 0) to_other = true;                    // only the strand that was not streamed can be called
-      else if (slow) to_redo = true;
+      else if (fl & F_SLOW) to_redo = true;
       else {                                                                  // evaluate the stream strand
         final_ = true;
         const uint32_t n = (uint32_t)__popcll(a0);
@@ -334,10 +340,10 @@ int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block) {
   const int nwb = (max_len + 31) / 32, nwn = (max_len + 63) / 64;
   const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4, pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
   const int64_t budget = (160 << 10) - 256;
-  int w = LANE_MAX_WAVES;
+  int w = 12;                                  // measured on c2: 12 waves per workgroup 8.2 ms, 16 waves 8.5 ms, 8 waves 8.5 ms
   if (const char* e = std::getenv("NB_LANE_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= LANE_MAX_WAVES) w = v; }
   while (w > 0 && pil + (int64_t)w * rec > budget) --w;
-  if (w < 4) return 0;                         // fewer than one wave per SIMD: not worth it
+  if (w < 8) return 0;                         // fewer than two waves per SIMD: the wave-per-read kernels take the batch
   if (waves_per_block) *waves_per_block = w;
   return pil + (int64_t)w * rec;
 }

@@ -37,15 +37,22 @@ def main(out, cfg="c2"):
     for tag in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_l1"):
         for f in find(os.path.join(out, tag), "*counter_collection.csv"):
             print(f"\n## {tag} ({os.path.relpath(f, out)}) — per-dispatch counter values of the alignment kernel")
-            agg = {}
+            # one step of the bench = every nb:: kernel of one nb_align_batch call (lane-per-read path: forward pass, reverse
+            # worklist, gather, wave-per-read kernel over the redo list, scatter): per-step value = sum over those kernels / steps,
+            # steps = dispatches of the kernel that ran most often among the dominant ones
+            agg, total = {}, {}
             for r in csv.DictReader(open(f)):
-                if "nb_align" not in r.get("Kernel_Name", ""):
+                if "nb::" not in r.get("Kernel_Name", ""):
                     continue
                 key = (r["Kernel_Name"][:60], r["Counter_Name"])
                 agg.setdefault(key, []).append(float(r["Counter_Value"]))
+            steps = max((len(v) for v in agg.values()), default=1)
             for (k, c), v in agg.items():
                 print(f"{k} {c}: dispatches={len(v)} mean={sum(v) / len(v):.1f} min={min(v):.1f} max={max(v):.1f}")
-                traffic[c] = sum(v) / len(v)
+                total[c] = total.get(c, 0.0) + sum(v)
+            for c, v in total.items():
+                traffic[c] = v / steps
+                print(f"ALL nb:: kernels {c}: per step = {v / steps:.1f}")
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
         # rocprofv3 reports both in KB per dispatch. FETCH_SIZE = TCC_EA0_RDREQ x 64 B (guide, MI355X_MICROARCH §HBM): for this
         # kernel's scattered 16-B probes / 8-B gathers each request is one 64-B fabric read, so no x2 streaming correction is
