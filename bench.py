@@ -338,7 +338,8 @@ def main():
         # L1->L2 request) from a table of this size, MEASURED by the standalone microbenchmark scripts/gather_bench.hip
         # (profiles/r02_gather_microbench.jsonl: 264 G requests/s from a 3 MB L2-resident table, 61 G from 49 MB in the Infinity Cache,
         # 55 G from 446 MB in HBM). achieved = L1->L2 read requests of the kernel (TCP_TCC_READ_REQ_sum of the committed PMC pass) / time.
-        "secondary_roofline": secondary_roofline(l2_requests, miss_requests, stats["table_bytes"] / 1e6, avg_kernel_s, n),
+        "secondary_roofline": secondary_roofline(l2_requests, miss_requests,
+                                                 (stats["ph_table_bytes"] if ctx.last_kernels()[0].startswith("nb_lane") else stats["table_bytes"]) / 1e6, avg_kernel_s, n),
         # what binds the kernel (profiles/r01_tuning_notes.md): instruction issue. Instructions issued per read (SQ counters of the
         # committed PMC pass) against the issue slots a SIMD has per read at this occupancy: above 1.0 = ports saturated.
         "issue": ({"instructions_per_read": sq["SQ_ACTIVE_INST_ANY"], "valu": sq["SQ_INSTS_VALU"], "salu": sq["SQ_INSTS_SALU"], "vmem": sq["SQ_INSTS_VMEM"],
@@ -350,6 +351,7 @@ def main():
         # C++ restatement), NOT parity with the Rust nimble-aligner, which stays unpinned (no binary, source or vectors offline)
         "oracle_self_consistency_ok": parity,
         "index": {"kmers": stats["n_kmers"], "colours": stats["n_colours"], "table_MB": stats["table_bytes"] / 1e6, "compact_table": bool(stats["compact"]),
+                  "perfect_hash_table_MB": stats["ph_table_bytes"] / 1e6, "perfect_hash_first_level_KB": stats["ph_pilot_bytes"] / 1e3,
                   "device_MB": stats["device_bytes"] / 1e6, "build_s": t_index},
         "per_cell": per_cell,
         "classes": int(glob_rows.shape[0]), "called_frac": float(reasons[0] / max(1, reasons.sum())), "readgen_s": t_gen,

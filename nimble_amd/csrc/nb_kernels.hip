@@ -1181,12 +1181,26 @@ int32_t nb_index_query(const nb_index* ix, const char* kmer, uint8_t* lext, uint
   if (h.compact) {
     const CProbe pr = compact_probe(canon, h.chash);
     const uint32_t wantk[2] = {pr.want | (uint32_t)o, pr.want | (uint32_t)o | 2u}; const uint32_t bs[2] = {pr.b1, pr.b2};
-    for (int t = 0; t < 2; ++t) for (int j = 0; j < 2; ++j) { const CEntry& e = h.ctable[bs[t]].e[j];
-        if (e.key == wantk[t] && e.pay != PAY_ABSENT) { const uint32_t p = e.pay;
-          if (rext) *rext = p & 15; if (lext) *lext = (p >> 4) & 15; if (r_int) *r_int = (p >> 8) & 1; if (l_int) *l_int = (p >> 9) & 1;
-          if (bits) std::memcpy(bits, h.eq_rows.data() + (size_t)(p >> 10) * h.words, (size_t)h.words * 8);
-          return 1; } }
-    return 0;
+    uint32_t pay = PAY_ABSENT;
+    for (int t = 0; t < 2; ++t) for (int j = 0; j < 2; ++j) { const CEntry& e = h.ctable[bs[t]].e[j]; if (e.key == wantk[t] && e.pay != PAY_ABSENT) pay = e.pay; }
+    if (h.has_ph) {
+      // the perfect-hash table of the lane-per-read kernels must say the same about this k-mer (present / absent on this strand, extension
+      // masks, class word): host-side cross-check of the second table, used by the index parity tests
+      const PHProbe q = ph_probe(canon, h.ph);
+      const PHEntry& e = h.ph_table[ph_slot(q, h.ph_pilots[q.group], h.ph)];
+      const uint32_t d = e.key ^ q.want;
+      const bool found = d < 4u, both = found && (d & 2u), mine = found && (both || (int)(d & 1u) == o);
+      bool ok = mine == (pay != PAY_ABSENT);
+      if (ok && mine && !both) {
+        const ColDesc& cd = h.desc[pay >> 10];
+        ok = (e.pay & 0x3FFu) == (pay & 0x3FFu) && (cd.nw == 1 ? (!(e.pay & (1u << 10)) && (e.pay >> 11) == cd.w0 && e.m == cd.m) : ((e.pay & (1u << 10)) && (e.pay >> 11) == (pay >> 10)));
+      }
+      if (!ok) { set_error("nb_index_query: the perfect-hash table disagrees with the compact table"); return NB_ERR_INVALID; }
+    }
+    if (pay == PAY_ABSENT) return 0;
+    if (rext) *rext = pay & 15; if (lext) *lext = (pay >> 4) & 15; if (r_int) *r_int = (pay >> 8) & 1; if (l_int) *l_int = (pay >> 9) & 1;
+    if (bits) std::memcpy(bits, h.eq_rows.data() + (size_t)(pay >> 10) * h.words, (size_t)h.words * 8);
+    return 1;
   }
   uint32_t b = kmer_bucket(canon, h.hash);
   for (;;) {

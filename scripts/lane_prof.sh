@@ -28,3 +28,6 @@ for tag in ("sq1", "sq2", "l2"):
         for (k, c), v in sorted(agg.items()):
             print(f"{k:48s} {c:22s} mean={sum(v)/len(v):.4g} n={len(v)}")
 PY
+# keep the merged-back output small (gpurun copies gpurun_out/ back only below 64 MiB): the per-dispatch traces are not needed once summarised
+# raw rocprofv3 output is summarised above; only the summaries travel back (gpurun merges gpurun_out/ only below 64 MiB)
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + 2>/dev/null || true

@@ -22,3 +22,5 @@ for f in sorted(glob.glob(os.path.join(out,'sq*','**','*counter_collection.csv')
     for k,v in agg.items(): print(f"{k}: {sum(v)/steps:.4g}")          # per step: summed over the kernels of one nb_align_batch call
     for (kn,c),v in sorted(per.items()): print(f"  {kn:44s} {c}: {sum(v)/len(v):.4g}")
 PY
+# raw rocprofv3 output is summarised above; only the summaries travel back (gpurun merges gpurun_out/ only below 64 MiB)
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + 2>/dev/null || true

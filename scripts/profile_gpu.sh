@@ -23,3 +23,6 @@ echo "== rocprofv3 PMC: TCP_TCC_READ_REQ_sum (optional) =="
 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/pmc_l1" -o bench -- python3 bench.py --steps 2 $Q > "$OUT/pmc_l1.json" 2> "$OUT/pmc_l1.err" || echo "(TCP_TCC_READ_REQ_sum not collected)"
 python scripts/summarize_profile.py "$OUT" "$CFG" > "$OUT/summary.txt"
 cat "$OUT/summary.txt"
+# keep what is merged back small (gpurun copies gpurun_out/ back only below 64 MiB)
+# raw rocprofv3 output is summarised above; only the summaries travel back (gpurun merges gpurun_out/ only below 64 MiB)
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} + 2>/dev/null || true

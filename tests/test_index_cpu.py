@@ -41,3 +41,31 @@ def test_colour_ids_ascend_by_size(built):
             q = ix.query(s[i:i + 20])
             sizes[tuple(q["members"])] = len(q["members"])
     assert len(sizes) == ix.stats()["n_colours"]
+
+
+def test_perfect_hash_table_agrees_with_compact_table(built):
+    """The BASELINE configs[1] library gets both tables: the compact cuckoo table (wave-per-read kernels) and the perfect-hash table
+    of the lane-per-read kernels. nb_index_query answers from the first and cross-checks the second on every call (presence on the
+    strand, extension masks, class word): stored k-mers, their reverse complements and random (absent) k-mers must all agree, and
+    presence must equal the oracle's."""
+    from oracle import oracle
+    _, seqs, strs, _ = library_strings(20, 50)
+    ix, ox = engine.Index(strs, 20), oracle.OracleIndex(strs, 20)
+    st = ix.stats()
+    assert st["compact"] == 1 and st["ph_table_bytes"] > 4_000_000 and 60_000 < st["ph_pilot_bytes"] <= 96 * 1024
+    assert st["words_internal"] == 20 and st["words_per_row"] == 16          # 20 loci x 50 alleles: one word per locus internally
+    rng = np.random.default_rng(1)
+    comp = str.maketrans("ACGT", "TGCA")
+    probes = []
+    for s in strs[::97]:
+        probes += [s[i:i + 20] for i in range(0, len(s) - 19, 7)]
+    probes += [p.translate(comp)[::-1] for p in probes[::3]]
+    probes += ["".join("ACGT"[c] for c in rng.integers(0, 4, 20)) for _ in range(20000)]
+    present = 0
+    for p in probes:
+        a, b = ix.query(p), ox.query(p)
+        assert (a is None) == (b is None), p
+        present += a is not None
+        if a is not None:
+            assert a["members"] == b["members"] and a["lext"] == b["lext"] and a["rext"] == b["rext"]
+    assert 1500 < present < len(probes) - 20000 + 50
