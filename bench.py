@@ -4,8 +4,8 @@
 Workload (BASELINE config 2): 10 M synthetic 150-bp single-end reads vs a 1 000-sequence HLA-like library
 (20 loci x 50 alleles, SURVEY.md §8d recipe), per GPU. A "step" = one pass of the alignment kernel over the whole
 batch. N > 1: one process per GPU (torchrun), reads sharded (each rank its own seeded batch, weak scaling), index
-replicated, no collective while aligning; the timed region ends with the dictionary agreement + ONE RCCL all-reduce
-of the per-class count vector. Prints ONE JSON line on rank 0.
+replicated, no collective while aligning; the timed region ends with the dictionary agreement (all-gather of 16-byte class
+digests) + ONE RCCL all-reduce of the per-class count vector (nimble_amd/merge.py). Prints ONE JSON line on rank 0.
 
 roofline.achieved = algorithmic bytes per read (ceil(2L/8) + ceil(L/8) + 8 = 65 B at L = 150) x reads per
 launch / average kernel duration measured with HIP events on the launch stream. cpu_baseline = the C++ oracle
@@ -151,7 +151,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from nimble_amd import distributed, engine, synth
+    from nimble_amd import engine, merge, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +212,8 @@ def main():
         b.record(stream)
     torch.cuda.synchronize()
     rows, counts = ctx.classes()
-    glob_rows, glob_counts = distributed.reduce_class_counts(rows, counts, device=cdev)
+    # end-of-job reduce (nimble_amd/merge.py): dictionary agreement by 16-byte digests, ONE all-reduce of the dense count vector, rows to rank 0
+    glob_rows, glob_counts = merge.reduce_class_counts_hashed(rows, counts, device=cdev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

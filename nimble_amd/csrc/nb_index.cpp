@@ -183,9 +183,9 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     for (int sidx = 0; sidx < n_seqs; ++sidx) ix->inv_perm[(size_t)ix->perm[(size_t)sidx]] = sidx;
   }
 
-  // 3b. device form of the colours: 16-byte descriptors in internal numbering + packed spans for the classes wider than a word
+  // 3b. device form of the colours: span descriptors in internal numbering (first two words inline) + packed spans for the wider ones
   ix->desc.resize(n_col);
-  ix->packed.assign(2, 0ull);
+  ix->packed.assign(1, 0ull);
   {
     std::vector<uint64_t> span;
     for (uint32_t c = 0; c < n_col; ++c) {
@@ -194,18 +194,15 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       for (uint64_t t = col_off[c]; t < col_off[c + 1]; ++t) { const uint32_t w = (uint32_t)ix->perm[pool[t]] >> 6; lo = std::min(lo, w); hi = std::max(hi, w); }
       span.assign((size_t)(hi - lo + 1), 0ull);
       for (uint64_t t = col_off[c]; t < col_off[c + 1]; ++t) { const uint32_t b = (uint32_t)ix->perm[pool[t]]; span[(b >> 6) - lo] |= 1ull << (b & 63); }
-      ColDesc d{}; d.w0 = lo; d.nw = hi - lo + 1;
+      ColDesc d{}; d.w0 = lo; d.nw = hi - lo + 1; d.size = ix->eq_sizes[id]; d.m0 = span[0]; d.m1 = d.nw > 1 ? span[1] : 0ull; d.off = 0;
       ix->max_desc_nw = std::max(ix->max_desc_nw, (int)d.nw);
-      if (d.nw == 1) d.m = span[0];
-      else {
-        if (ix->packed.size() & 1) ix->packed.push_back(0ull);                       // spans start 16-byte aligned
+      if (d.nw > 2) {
         if (ix->packed.size() + d.nw > 0xFFFFFFFFull) { delete ix; set_error("nb_index_build: packed colour spans exceed 2^32 words"); return NB_ERR_UNSUPPORTED; }
-        d.m = (uint64_t)ix->packed.size();
+        d.off = (uint32_t)ix->packed.size();
         ix->packed.insert(ix->packed.end(), span.begin(), span.end());
       }
       ix->desc[id] = d;
     }
-    if (ix->packed.size() & 1) ix->packed.push_back(0ull);
   }
 
   // 4. unitig-interior flags (SPEC §2, local rule). recs is sorted by k-mer.
@@ -264,7 +261,9 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     static const uint32_t MULS[4][2] = {{0x9E3779B1u, 0x85EBCA77u}, {0xC2B2AE3Du, 0x27D4EB2Fu}, {0x165667B1u, 0x9E3779B9u}, {0xD3A2646Du, 0xFD7046C5u}};
     double load = COMPACT_LOAD;
     bool done = false;
-    for (int attempt = 0; attempt < 12 && !done; ++attempt, load *= (attempt % 4 == 0 ? 0.93 : 1.0)) {
+    // (a canonical k-mer present on BOTH strands needs two of the four slots of its bucket pair: a library that holds sequences and their
+    //  reverse complements only fills to about half the usual load, hence the long tail of attempts)
+    for (int attempt = 0; attempt < 40 && !done; ++attempt, load *= (attempt % 2 == 0 ? 0.92 : 1.0)) {
       CHash h{}; h.a = MULS[attempt % 4][0]; h.c = MULS[attempt % 4][1]; h.hb = hb; h.himask = hb ? ((1u << hb) - 1u) : 0u;
       uint64_t nb64 = std::max<uint64_t>(nb_min, (uint64_t)((double)n_entries / (2.0 * load)) + 1);
       if (nb64 > 0x7FFFFFFFull) break;
@@ -361,7 +360,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
           const ColDesc& d = ix->desc[colour];
           PHEntry en; en.key = q.want | (both ? 2u : 0u) | (uint32_t)strand;
           en.pay = (pay & 0x3FFu) | (d.nw == 1 ? (d.w0 << 11) : ((1u << 10) | (colour << 11)));
-          en.m = d.nw == 1 ? d.m : 0ull;
+          en.m = d.nw == 1 ? d.m0 : 0ull;
           if (en.key == 0xFFFFFFFFu || d.w0 > 0x1FFFFFu || colour > 0x1FFFFFu) bad_key = true;
           tab[ph_slot(q, pilots[q.group], h)] = en;
         }

@@ -143,19 +143,24 @@ NB_HD inline uint32_t ph_slot(const PHProbe& p, uint32_t pilot, const PHash& h) 
   return s >= h.n_slots ? s - h.n_slots : s;
 }
 
-// A colour (equivalence class of the graph) on the device, 16 bytes, one dwordx4. Bit positions are INTERNAL sequence numbers: the
-// index builder renumbers the sequences so that every connected component of the "share a k-mer" relation (a locus, for a
-// gene-family library) starts at a 64-bit word boundary or lies inside one word (nb_index.cpp, step 3a). A class is a subset of one
-// component, so classes of components of <= 64 sequences occupy exactly ONE word: nw == 1 and `m` is that word — intersecting a
-// read's classes then needs nothing but these 16 bytes per k-mer position. Classes of larger components keep their nw words in
-// `packed` at [(uint32_t)m, +nw), 16-byte aligned. Rows of the class table are in internal numbering too; the C-ABI converts them
-// back (nb_classes_read), so callers only ever see original sequence indices.
+// A colour (equivalence class of the graph) for the wave-per-read kernels: the span of u64 words of its bitset that can be non-zero, with
+// the first two words inline (32 bytes, two dwordx4 issued together). Bit positions are INTERNAL sequence numbers: the index builder
+// renumbers the sequences so that every connected component of the "share a k-mer" relation (a locus, for a gene-family library) starts
+// at a 64-bit word boundary or lies inside one word (nb_index.cpp, step 3a). A class is a subset of one component, so classes of
+// components of <= 64 sequences occupy exactly ONE word and those of components of <= 128 sequences two: intersecting a read's classes
+// needs nothing but the descriptors. Wider classes keep their span in `packed` at [off, off + nw). (The lane-per-read kernels do not
+// load descriptors at all: their table entries carry the class word, PHEntry above.) Rows of the class table are in internal numbering
+// too; the C-ABI converts them back (nb_classes_read), so callers only ever see original sequence indices.
+// (Measured: a 16-byte form with only one word inline cost the 10 000-sequence library, whose 100-allele loci span two words, a
+// dependent `packed` load per visited position: 314 vs 285 ms per 100 M reads.)
 struct ColDesc {
   uint32_t w0;     // first word of the span (internal numbering)
   uint32_t nw;     // words in the span (>= 1)
-  uint64_t m;      // nw == 1: the word; nw > 1: index into packed[] of the span
+  uint32_t off;    // index into packed[] of the span (valid when nw > 2)
+  uint32_t size;   // members (popcount)
+  uint64_t m0, m1; // words w0 and w0 + 1
 };
-static_assert(sizeof(ColDesc) == 16, "descriptor must be 16 bytes");
+static_assert(sizeof(ColDesc) == 32, "descriptor must be 32 bytes");
 
 inline uint32_t make_payload(uint32_t colour, uint32_t lext, uint32_t rext, uint32_t r_int, uint32_t l_int) {
   return (colour << 10) | (l_int << 9) | (r_int << 8) | (lext << 4) | rext;

@@ -100,11 +100,12 @@ template <int NR> struct Strand {
 // wave AND-reduction folds them. Typical reads (all classes inside one locus) need ONE memory round trip here (the
 // descriptors) instead of the seed-row + per-word gather of a dense-row layout. Prefetching the descriptors before the
 // walk was tried and lost (112 VGPRs -> 4 waves/SIMD, 18.8 ms vs 17.8 ms). acc[t] (lane l) = word l + 64 t. Returns |eq|.
-struct DescRegs { uint32_t w0, nw; uint64_t m; };   // ColDesc in registers (nb_internal.h): nw == 1 -> m is the word, else the index of the span in `packed`
+struct DescRegs { uint32_t w0, nw, off; uint64_t m0, m1; };
 
 __device__ __forceinline__ DescRegs load_desc(const DevIndex& ix, uint32_t colour) {
-  const uint4 a = *reinterpret_cast<const uint4*>(&ix.desc[colour]);
-  DescRegs d; d.w0 = a.x; d.nw = a.y; d.m = ((uint64_t)a.w << 32) | a.z;
+  const uint4* p = reinterpret_cast<const uint4*>(&ix.desc[colour]);
+  const uint4 a = p[0], b = p[1];
+  DescRegs d; d.w0 = a.x; d.nw = a.y; d.off = a.z; d.m0 = ((uint64_t)b.y << 32) | b.x; d.m1 = ((uint64_t)b.w << 32) | b.z;
   return d;
 }
 // bit `lane` of a wave-UNIFORM 64-bit mask as a per-lane boolean: the mask's SGPR pair is used as the lane mask of a
@@ -127,13 +128,13 @@ __device__ __forceinline__ uint32_t intersect_descs(const DevIndex& ix, const St
 #pragma unroll
   for (int t = 0; t < TW; ++t) acc[t] = 0ull;
   uint32_t n = 0;
-  for (uint32_t j = lo; j < hi; ++j) {            // wave-uniform; one word for components of <= 64 sequences
+  for (uint32_t j = lo; j < hi; ++j) {            // wave-uniform; one word for components of <= 64 sequences, two up to 128
     uint64_t v = ~0ull; bool need = false;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { if (d[r].nw == 1u) v &= d[r].m; else need = true; }   // (a one-word span inside the window IS word j)
-    if (__ballot(need)) {                          // some class is wider than one word here: its span lives in `packed`
+    for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { const uint32_t idx = j - d[r].w0; need |= idx >= 2u; v &= idx == 0u ? d[r].m0 : (idx == 1u ? d[r].m1 : ~0ull); }
+    if (__ballot(need)) {                          // some class is wider than its two inline words here
 #pragma unroll
-      for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r]) && d[r].nw != 1u) v &= ix.packed[(size_t)(uint32_t)d[r].m + (j - d[r].w0)];
+      for (int r = 0; r < NR; ++r) if (lane_bit(S.V.w[r])) { const uint32_t idx = j - d[r].w0; if (idx >= 2u) v &= ix.packed[(size_t)d[r].off + idx]; }
     }
     v = wave_and_u64(v);
     n += (uint32_t)__popcll(v);
@@ -246,7 +247,8 @@ __device__ __forceinline__ int map_both_strands_fast(const DevIndex& ix, const u
     for (int r = 0; r < NR; ++r) {
       const uint32_t colour = lane_bit(H.w[r]) ? col[r] : 0u;
       const char* g = reinterpret_cast<const char*>(&ix.desc[colour]);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[r][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[2 * r][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16), (__attribute__((address_space(3))) void*)&lds[2 * r + 1][0], 16, 0, 0);
     }
   };
   {
@@ -525,7 +527,8 @@ __device__ __forceinline__ int tri_finish(const DevIndex& ix, const TriProbe<CT>
     for (int r = 0; r < 3; ++r) {
       const uint32_t colour = lane_bit(H.m[r]) ? col[r] : 0u;
       const char* g = reinterpret_cast<const char*>(&ix.desc[colour]);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[r][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)&lds[2 * r][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16), (__attribute__((address_space(3))) void*)&lds[2 * r + 1][0], 16, 0, 0);
     }
   };
   if (lds && anyF) { pre = 1; fetch_descs(HF, F.col); }
@@ -646,7 +649,7 @@ template <int NR, int TW, bool TRI, bool CT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES_PER_EU))) void nb_align_se_kernel(DevIndex ix, DevClasses ctv, const DevClasses* __restrict__ ctp, BatchArgs a, const uint64_t* __restrict__ reads_ro) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   constexpr bool LDS_DESC = TW == 1 && (TRI || NR == 2);   // (wide class rows go through `packed` anyway: a loss on c5; one round of positions: neutral)
-  __shared__ uint4 s_desc[LDS_DESC ? 4 : 1][LDS_DESC ? NR : 1][LDS_DESC ? 64 : 1];   // per wave: one 16-byte descriptor per lane and residue / round
+  __shared__ uint4 s_desc[LDS_DESC ? 4 : 1][LDS_DESC ? 2 * NR : 1][LDS_DESC ? 64 : 1];   // per wave: 3 residues x 2 halves of a 32-byte descriptor per lane
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -716,8 +719,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
               for (int rr = 0; rr < NR; ++rr) {
-                const uint4 da = s_desc[wave][rr][lane];
-                d[rr].w0 = da.x; d[rr].nw = da.y; d[rr].m = ((uint64_t)da.w << 32) | da.z;
+                const uint4 da = s_desc[wave][2 * rr][lane], db = s_desc[wave][2 * rr + 1][lane];
+                d[rr].w0 = da.x; d[rr].nw = da.y; d[rr].off = da.z; d[rr].m0 = ((uint64_t)db.y << 32) | db.x; d[rr].m1 = ((uint64_t)db.w << 32) | db.z;
               }
             }
             n = isR ? intersect_descs<NR, TW>(ix, SR, d, lane, acc) : intersect_descs<NR, TW>(ix, SF, d, lane, acc);
@@ -1193,7 +1196,7 @@ int32_t nb_index_query(const nb_index* ix, const char* kmer, uint8_t* lext, uint
       bool ok = mine == (pay != PAY_ABSENT);
       if (ok && mine && !both) {
         const ColDesc& cd = h.desc[pay >> 10];
-        ok = (e.pay & 0x3FFu) == (pay & 0x3FFu) && (cd.nw == 1 ? (!(e.pay & (1u << 10)) && (e.pay >> 11) == cd.w0 && e.m == cd.m) : ((e.pay & (1u << 10)) && (e.pay >> 11) == (pay >> 10)));
+        ok = (e.pay & 0x3FFu) == (pay & 0x3FFu) && (cd.nw == 1 ? (!(e.pay & (1u << 10)) && (e.pay >> 11) == cd.w0 && e.m == cd.m0) : ((e.pay & (1u << 10)) && (e.pay >> 11) == (pay >> 10)));
       }
       if (!ok) { set_error("nb_index_query: the perfect-hash table disagrees with the compact table"); return NB_ERR_INVALID; }
     }
@@ -1302,7 +1305,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   // gathered and goes through the wave-per-read kernel below.
   const char* lane_env = std::getenv("NB_LANE");
   int lane_wpb = 0;
-  if (!d_mates && cfg->num_mismatches == 0 && c->has_ph && positions >= 1 && !(lane_env && lane_env[0] == '0') && lane_lds_bytes(c, max_len, &lane_wpb) > 0) {
+  if (!d_mates && cfg->num_mismatches == 0 && c->has_ph && positions >= 1 && n < (1ll << 31) && !(lane_env && lane_env[0] == '0') && lane_lds_bytes(c, max_len, &lane_wpb) > 0) {
     const int64_t stride = a.stride;
     if (c->lists_cap < n) {
       (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;

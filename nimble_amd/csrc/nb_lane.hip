@@ -170,23 +170,38 @@ __global__ __launch_bounds__(768) void nb_lane_kernel(LaneHead h, const LaneTail
       }
       rcf = votes < 0;
     }
-    // ---- stream state ----
+    // ---- stream state: the next bases / N bits of the stream in two per-lane shift registers, refilled 16 at a time ----
     uint64_t fw = 0, rv = 0;
     int nvalid = 0;
     uint32_t prevb = 0;
-    auto advance = [&](int t) {                 // consume stream base t; afterwards fw / rv = the k-mer ending at base t and its reverse complement
-      const bool in = t < L;
-      const int jj = in ? (rcf ? L - 1 - t : t) : 0;
-      const uint32_t bw = rec[(jj >> 4) * 64 + lane], nw = rec[(2 * nwb + (jj >> 5)) * 64 + lane];
-      uint32_t b = (bw >> ((jj & 15) * 2)) & 3u;
-      const bool isn = (nw >> (jj & 31)) & 1u;
-      b = rcf ? 3u - b : b;
-      prevb = (uint32_t)fw & 3u;                // first base of the k-mer that ended at t - 1 = the base before the new k-mer
+    uint64_t bq = 0; uint32_t nq = 0;            // upcoming stream bases (2 bits each, next one at bit 0) / their N-or-beyond-the-read bits
+    int avail = 0, snext = 0;                    // wave-uniform: bases held, stream index of the next chunk
+    auto refill = [&]() {                        // append stream bases [snext, snext + 16): forward lanes read one dword of their record,
+      int hi = L - 1 - snext; hi = hi < 0 ? 0 : hi;                  // reverse lanes the 16 bases ENDING at read base hi, reversed and complemented
+      const int jb_f = snext >> 4, jb_r = hi >> 4, jb_r1 = jb_r > 0 ? jb_r - 1 : 0;
+      const uint32_t A = rec[(rcf ? jb_r : jb_f) * 64 + lane], Bw = rec[(rcf ? jb_r1 : jb_f) * 64 + lane];
+      uint32_t win = (uint32_t)((((uint64_t)A << 32) | Bw) >> (rcf ? 2 * ((hi & 15) + 1) : 32));
+      uint32_t rev = __brev(win); rev = ((rev & 0x55555555u) << 1) | ((rev >> 1) & 0x55555555u);
+      win = rcf ? ~rev : win;
+      const int nb0 = 2 * nwb, jn_f = snext >> 5, jn_r = hi >> 5, jn_r1 = jn_r > 0 ? jn_r - 1 : 0;
+      const uint32_t NA = rec[(nb0 + (rcf ? jn_r : jn_f)) * 64 + lane], NB = rec[(nb0 + (rcf ? jn_r1 : jn_f)) * 64 + lane];
+      uint32_t nwin = (uint32_t)((((uint64_t)NA << 32) | NB) >> (rcf ? (hi & 31) + 17 : 32 + (snext & 16))) & 0xFFFFu;
+      nwin = rcf ? (__brev(nwin) >> 16) : nwin;
+      const int left = L - snext;                                     // stream positions of this chunk that lie inside the read
+      nwin |= left >= 16 ? 0u : (left <= 0 ? 0xFFFFu : ((0xFFFFu << left) & 0xFFFFu));
+      bq |= (uint64_t)win << (2 * avail); nq |= nwin << avail;
+      avail += 16; snext += 16;
+    };
+    auto advance = [&]() {                       // consume the next stream base: fw / rv = the k-mer ending there and its reverse complement
+      const uint32_t b = (uint32_t)bq & 3u;
+      const bool isn = nq & 1u;
+      bq >>= 2; nq >>= 1; --avail;
+      prevb = (uint32_t)fw & 3u;                // first base of the k-mer that ended one base earlier = the base before the new k-mer
       fw = (fw >> 2) | ((uint64_t)b << top);
       rv = ((rv << 2) | (uint64_t)(3u - b)) & kmask;
-      nvalid = (in && !isn) ? nvalid + 1 : 0;
+      nvalid = isn ? 0 : nvalid + 1;
     };
-    for (int t = 0; t < K - 1; ++t) advance(t);
+    for (int t = 0; t < K - 1; ++t) { if (avail == 0) refill(); advance(); }
 
     // ---- online walk of the stream strand (docs/SPEC.md §3) ----
     int mode = 0, cnt = 0, cov = 0, cl = 0;     // mode 0 = seeking a seed, 1 = inside a run, 2 = done; cl = consecutive LX bits ending here
@@ -201,35 +216,39 @@ __global__ __launch_bounds__(768) void nb_lane_kernel(LaneHead h, const LaneTail
     struct Blk { uint32_t want[4], meta[4]; uint4 e[4]; };
     Blk A, B;
     auto probe_block = [&](Blk& X, int p0) {
+      if (avail < 4) refill();
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        advance(p0 + u + K - 1);
+        advance();
         const bool valid = nvalid >= K;
         const bool o = fw > rv;
         const PHProbe pr = ph_probe(o ? rv : fw, h.ph);
         X.want[u] = pr.want;
-        X.meta[u] = (valid ? 1u : 0u) | (o ? 2u : 0u) | (nvalid >= K + 1 ? 4u : 0u) | (prevb << 3);
+        const uint32_t nv = (uint32_t)(nvalid < 31 ? nvalid : 31);          // meta: run of valid bases (clamped) | o << 5 | previous base << 6
+        X.meta[u] = nv | (o ? 32u : 0u) | (prevb << 6);
         X.e[u] = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_lookup_slot(h, s_pilots, pr) : 0u]);
       }
     };
     uint64_t curH = 0, curR = 0;
     auto walk_block = [&](const Blk& X, int p0, int q) {
+      uint32_t bitsH = 0, bitsR = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int p = p0 + u;
         const uint32_t d = X.e[u].x ^ X.want[u], mt = X.meta[u], pay = X.e[u].y;
-        const bool found = (mt & 1u) && d < 4u;
+        const int nv = (int)(mt & 31u);
+        const bool found = nv >= K && d < 4u;
         const bool both = found && (d & 2u);
-        const bool hS = found && !both && ((d & 1u) == ((mt >> 1) & 1u));
+        const bool hS = found && !both && ((d & 1u) == ((mt >> 5) & 1u));
         const bool hO = found && !both && !hS;
         fl |= both ? F_HARD : 0u;
-        const bool prev_ok = mt & 4u;
-        const uint32_t pb = (mt >> 3) & 3u;
+        const bool prev_ok = nv >= K + 1;
+        const uint32_t pb = (mt >> 6) & 3u;
         const bool lxS = hS && prev_ok && ((pay >> (4u + pb)) & 1u);
         if (PASS == 0) {
           const bool rrO = hO && prev_ok && ((pay >> (3u - pb)) & 1u);
-          curH |= (uint64_t)(hO ? 1u : 0u) << (q + u);
-          curR |= (uint64_t)(rrO ? 1u : 0u) << (q + u);
+          bitsH |= (hO ? 1u : 0u) << u;          // (u is a compile-time constant: one v_lshl_or each; folded into the 64-bit word once per block)
+          bitsR |= (rrO ? 1u : 0u) << u;
         }
         // one step of SPEC §3 at position p, as selects
         const bool is_run = mode == 1;
@@ -251,6 +270,7 @@ __global__ __launch_bounds__(768) void nb_lane_kernel(LaneHead h, const LaneTail
         lo = first ? w0 : lo;
         fl |= (seed ? F_SEEDED : 0u) | (visit ? F_STARTED : 0u) | ((lext || (visit && (pay & (1u << 10)))) ? F_SLOW : 0u);   // (a class wider than one word: slow too)
       }
+      if (PASS == 0) { curH |= (uint64_t)bitsH << q; curR |= (uint64_t)bitsR << q; }
     };
     if (Pmax > 0) probe_block(A, 0);
 #pragma unroll 1
@@ -350,8 +370,8 @@ int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block) {
 
 template <int NR, int PASS>
 static int launch_lane_t(nb_ctx* c, const LaneHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
-  static thread_local bool attr_set = false;
-  if (!attr_set) { NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_lane_kernel<NR, PASS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
+  // (per launch: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may hold contexts on several)
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_lane_kernel<NR, PASS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
   const long long need = PASS == 0 ? (h.n + 64LL * waves - 1) / (64LL * waves) : blocks;     // pass 1: the list length is only known on the device
   if (blocks > need) blocks = need;

@@ -76,6 +76,22 @@ def test_wide_library_multiword_rows(built):
     assert_same(gpu, ora, "wide")
 
 
+def test_library_with_both_strands(built):
+    """A library that holds sequences AND reverse complements of (other) sequences: k-mers present on both strands, reads whose two
+    orientations are both viable (ties go to F, the better coverage wins otherwise). In the lane-per-read path these are exactly the
+    reads handed to the wave-per-read kernel (k-mer on both strands / both strands viable): the redo list must reproduce the oracle."""
+    _, seqs, strs, _ = library_strings(3, 6, locus_len=500, seed=31)
+    comp = str.maketrans("ACGT", "TGCA")
+    strs = strs + [s.translate(comp)[::-1] for s in strs[:9]] + [strs[10][:250] + strs[11].translate(comp)[::-1][250:]]
+    seqs2 = [np.frombuffer(s.encode(), dtype=np.uint8) for s in strs]
+    lut = np.zeros(256, dtype=np.uint8); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
+    codes = synth.synth_reads([lut[x] for x in seqs2], 6000, 150, seed=19, err=0.015)
+    for kw in (dict(), dict(strand_filter="fiveprime"), dict(discard_multiple_matches=True)):
+        gpu, ora = _both(strs, 20, engine.make_config(**kw), codes)
+        assert (ora["reason"] == 0).sum() > 3000
+        assert_same(gpu, ora, f"both strands {kw}")
+
+
 def test_ragged_and_edge_reads(built):
     """Variable lengths (incl. shorter than k and empty), all-N reads, exact reference substrings, reverse complements."""
     _, seqs, strs, _ = library_strings(3, 5, locus_len=400, seed=21)

@@ -28,3 +28,23 @@ def test_bench_json_line():
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert j["oracle_self_consistency_ok"] is True
+
+
+def test_bench_two_ranks_rehearsal():
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this box's one GPU
+    with two ranks sharing it and gloo for the collectives (on a multi-GPU node the same code runs over RCCL): barrier + max-over-ranks
+    timing, digest-first class dictionary agreement, one all-reduce of the count vector; value = reads of ALL ranks / time."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "300000", "--backend", "gloo",
+                        "--cpu-sample", "0", "--parity-sample", "3000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["reads_per_gpu"] == 300000 and j["oracle_self_consistency_ok"] is True
+    assert j["cpu_baseline"] is None and j["classes"] > 1000
+    assert abs(j["value"] - 2 * 300000 * 2 / (j["ms_per_step"] * 2 / 1e3) / 1e6) < 1e-6 * j["value"] + 1e-9

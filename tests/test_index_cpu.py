@@ -69,3 +69,20 @@ def test_perfect_hash_table_agrees_with_compact_table(built):
         if a is not None:
             assert a["members"] == b["members"] and a["lext"] == b["lext"] and a["rext"] == b["rext"]
     assert 1500 < present < len(probes) - 20000 + 50
+
+
+def test_index_with_reverse_complement_sequences(built):
+    """A library that contains sequences and reverse complements of sequences: most canonical k-mers are present on BOTH strands (two
+    entries per bucket pair in the compact table: it fills to about half the usual load; `both` entries in the perfect-hash table)."""
+    from oracle import oracle
+    _, _, strs, _ = library_strings(3, 6, locus_len=500, seed=31)
+    comp = str.maketrans("ACGT", "TGCA")
+    strs = strs + [s.translate(comp)[::-1] for s in strs[:9]] + [strs[10][:250] + strs[11].translate(comp)[::-1][250:]]
+    ix, ox = engine.Index(strs, 20), oracle.OracleIndex(strs, 20)
+    st = ix.stats()
+    assert st["n_kmers"] == ox.num_kmers and st["n_canonical"] < 0.7 * st["n_kmers"] and st["compact"] == 1
+    rng = np.random.default_rng(4)
+    probes = [s[i:i + 20] for s in strs[::3] for i in range(0, len(s) - 19, 5)]
+    probes += [p.translate(comp)[::-1] for p in probes[::2]] + ["".join("ACGT"[c] for c in rng.integers(0, 4, 20)) for _ in range(3000)]
+    for p in probes:
+        assert ix.query(p) == ox.query(p), p
