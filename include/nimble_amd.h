@@ -152,6 +152,12 @@ int32_t nb_counts_device_ptr(nb_ctx* ctx, void** d_counts, int64_t* capacity);
 typedef struct nb_fastq nb_fastq;
 int32_t nb_fastq_open(const char* path, nb_fastq** out);
 int32_t nb_fastq_close(nb_fastq* fq);
+/* several ranks, one input: a byte range [begin, end) (end < 0: to the end) of a PLAIN FASTQ file that starts at a record boundary
+ * (NB_ERR_UNSUPPORTED for compressed files: they cannot be entered in the middle); the helpers below find such boundaries:
+ * newlines in a byte range (+ its last byte, -1 if empty) and the offset just behind the n-th newline at or after `begin` (-1: fewer) */
+int32_t nb_fastq_open_range(const char* path, int64_t begin, int64_t end, nb_fastq** out);
+int32_t nb_file_count_newlines(const char* path, int64_t begin, int64_t end, int64_t* count_out, int32_t* last_byte_out);
+int32_t nb_file_nth_newline(const char* path, int64_t begin, int64_t n, int64_t* offset_out);
 /* worker threads used to pack a batch (the reference's -c/--num_cores, __main__.py:398); default 1 */
 int32_t nb_fastq_set_threads(nb_fastq* fq, int32_t threads);
 int32_t nb_fastq_next_batch(nb_fastq* fq, int64_t max_reads, int32_t max_len, uint64_t* out_words, uint16_t* out_lens,

@@ -72,6 +72,9 @@ SIGNATURES = {
                                     ct.c_int64, ct.POINTER(ct.c_char_p), ct.c_double, ct.c_int32, ct.c_char_p, c_i64p]),
     "nb_fastq_open": (ct.c_int32, [ct.c_char_p, ct.POINTER(ct.c_void_p)]),
     "nb_fastq_close": (ct.c_int32, [ct.c_void_p]),
+    "nb_fastq_open_range": (ct.c_int32, [ct.c_char_p, ct.c_int64, ct.c_int64, ct.POINTER(ct.c_void_p)]),
+    "nb_file_count_newlines": (ct.c_int32, [ct.c_char_p, ct.c_int64, ct.c_int64, c_i64p, ct.POINTER(ct.c_int32)]),
+    "nb_file_nth_newline": (ct.c_int32, [ct.c_char_p, ct.c_int64, ct.c_int64, c_i64p]),
     "nb_fastq_set_threads": (ct.c_int32, [ct.c_void_p, ct.c_int32]),
     "nb_fastq_index_batch": (ct.c_int32, [ct.c_void_p, ct.c_int64, c_i64p, ct.POINTER(ct.c_int32)]),
     "nb_fastq_next_batch_tight": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.c_int32, ct.c_void_p, ct.c_void_p, c_i64p, ct.POINTER(ct.c_int32),

@@ -55,9 +55,13 @@ class FastqReader:
     (the top-up of a batch that ended early, _top_up) reads into a third, private buffer set and does not advance the
     turn, so it can never land in the buffers of the batch that is still being uploaded."""
 
-    def __init__(self, path, threads=1, pinned=False):
+    def __init__(self, path, threads=1, pinned=False, byte_range=None):
+        """byte_range = (begin, end) of a plain FASTQ file, begin at a record boundary: the share of one rank (plan_ranges)."""
         self._h = ct.c_void_p()
-        _lib.check(_lib.lib().nb_fastq_open(path.encode(), ct.byref(self._h)))
+        if byte_range is None:
+            _lib.check(_lib.lib().nb_fastq_open(path.encode(), ct.byref(self._h)))
+        else:
+            _lib.check(_lib.lib().nb_fastq_open_range(path.encode(), int(byte_range[0]), int(byte_range[1]), ct.byref(self._h)))
         _lib.check(_lib.lib().nb_fastq_set_threads(self._h, int(threads)))
         self._pinned = pinned
         self._sets, self._turn = {}, 0
@@ -401,9 +405,13 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
         corrector = None
         if tenx is not None and tenx.whitelist:
             corrector = NativeWhitelist(tenx.whitelist, num_cores)
+        # several ranks: each rank reads its own byte range of plain FASTQ input (plan_ranges); compressed / BAM input is read in full by
+        # every rank and the batches are dealt round-robin instead
+        plan = plan_ranges(input, world, rank) if world > 1 and not is_bam and os.environ.get("NB_RANGE_SHARDING", "1") != "0" else None
+        ranges = plan["ranges"] if plan else None
         bam = BamReader(input[0], num_cores, pinned=True) if is_bam else None
-        r1 = FastqReader(input[0], num_cores, pinned=True) if not is_bam else None
-        r2 = FastqReader(input[1], num_cores, pinned=True) if len(input) == 2 else None
+        r1 = FastqReader(input[0], num_cores, pinned=True, byte_range=ranges[0] if ranges else None) if not is_bam else None
+        r2 = FastqReader(input[1], num_cores, pinned=True, byte_range=ranges[1] if ranges else None) if len(input) == 2 else None
         total, t0 = 0, time.time()
         prof = _StageClock()
 
@@ -459,9 +467,10 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
                 break
             pending = pool.submit(fetch)
             batch_index += 1
-            if batch_index % world != rank:   # several ranks: batches are dealt round-robin; every rank walks the whole input, aligns its share
-                total += n
+            if ranges is None and batch_index % world != rank:   # several ranks without byte ranges: batches are dealt round-robin (every rank
+                total += n                                         # walks the whole input and aligns its share)
                 continue
+            part_key = batch_index if ranges is None else (rank << 32) + batch_index   # order of the parts in the per-read table = input order
             with prof("H2D"):
                 words, max_len = _tight(seq)
                 d_reads = torch.from_numpy(words.view(np.int64)).to(dev, non_blocking=True)
@@ -496,12 +505,18 @@ def align(reference, output, input, num_cores=1, strand_filter="unstranded", tri
                         snap = run.snapshot()
                     write_jobs.append(writer.submit(_timed, prof, "TSV rows (writer thread)", _write_per_read, run, snap, h_class.numpy().view(np.uint32),
                                                     h_info.numpy().view(np.uint32), h_cov.numpy().view(np.uint64), b1["cb_fixed"], b1["cb_ok"],
-                                                    b1["umi"].copy(), batch_index))   # (reader buffers are recycled two batches on)
+                                                    b1["umi"].copy(), part_key))   # (reader buffers are recycled two batches on)
             total += n
         with prof("wait for writer"):
             for j in write_jobs:
                 j.result()
         writer.shutdown(wait=True)
+        if plan is not None:
+            import torch.distributed as dist
+            check_range_complete(plan, total)
+            t = torch.tensor([total], dtype=torch.int64, device=cdev)
+            dist.all_reduce(t)
+            total = int(t[0])                 # templates of the whole job, as every rank counts them without byte ranges
         for run in runs:
             run.finish(cdev)
             reasons = run.ctx.reasons()
@@ -546,6 +561,86 @@ def _warn_not_honoured(msg):
     accept such an option silently; the exit code stays 0 because the run itself is valid for untrimmed / unfiltered input)."""
     print(f"Warning -- not honoured: {msg}", file=sys.stderr)
     sys.stderr.flush()
+
+
+def plan_ranges(paths, world, rank):
+    """Several ranks, plain FASTQ input: the byte range of every input file that THIS rank reads, so that each rank parses 1/world of
+    the text instead of all of it. Every rank counts the newlines of one slice of each file (nb_file_count_newlines), the counts are
+    all-gathered, records (4 lines) are dealt in contiguous blocks — the same record numbers in R1 and R2 — and each rank locates the byte
+    offsets of its first and last line inside one slice (nb_file_nth_newline). Returns {"ranges": [(begin, end), ...], "records": the
+    number of records this rank must find in each range (check_range_complete)} or None when the input cannot be entered in the middle
+    (gzip / BGZF / BAM), is not four lines per record or the files disagree: the ranks then deal batches round-robin."""
+    import torch.distributed as dist
+    L = _lib.lib()
+    mine, ok = [], True
+    for path in paths:
+        size = os.path.getsize(path)
+        with open(path, "rb") as f:
+            magic = f.read(2)
+        if magic == b"\x1f\x8b" or path.lower().endswith(".bam"):
+            ok = False
+            break
+        lo, hi = size * rank // world, size * (rank + 1) // world
+        cnt, last = ct.c_int64(), ct.c_int32()
+        _lib.check(L.nb_file_count_newlines(path.encode(), lo, hi, ct.byref(cnt), ct.byref(last)))
+        mine.append((size, cnt.value, last.value))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, (ok, mine))
+    if not all(e[0] for e in everyone):
+        return None
+    ranges, n_records = [], None
+    for i, path in enumerate(paths):
+        size = mine[i][0]
+        counts = [e[1][i][1] for e in everyone]
+        last_byte = next((e[1][i][2] for e in reversed(everyone) if e[1][i][2] >= 0), -1)
+        lines = sum(counts) + (1 if size > 0 and last_byte != 10 else 0)
+        if lines % 4:
+            ranges = None
+            break
+        recs = lines // 4
+        if n_records is None:
+            n_records = recs
+        elif recs != n_records:                        # blank lines, or really different: the whole-file readers find out which
+            ranges = None
+            break
+
+        def line_offset(l):
+            """byte offset at which line l (0-based) starts"""
+            if l <= 0:
+                return 0
+            if l >= lines:
+                return size
+            acc = 0
+            for s_, c in enumerate(counts):
+                if acc + c >= l:                       # the l-th newline of the file is the (l - acc)-th of slice s_
+                    off = ct.c_int64()
+                    _lib.check(L.nb_file_nth_newline(path.encode(), size * s_ // world, l - acc, ct.byref(off)))
+                    return off.value
+                acc += c
+            return size
+        ranges.append((line_offset(4 * (recs * rank // world)), line_offset(4 * (recs * (rank + 1) // world))))
+    good = ranges is not None
+    if good:                                           # strict framing at the range starts: '@' line, sequence, '+' line
+        for path, (b, e) in zip(paths, ranges):
+            if e > b:
+                with open(path, "rb") as f:
+                    f.seek(b)
+                    head = f.read(1 << 16).split(b"\n")
+                good = good and head[0][:1] == b"@" and (len(head) < 3 or head[2][:1] == b"+")
+    verdicts = [None] * world
+    dist.all_gather_object(verdicts, good)
+    if not all(verdicts):
+        return None
+    return {"ranges": ranges, "records": n_records * (rank + 1) // world - n_records * rank // world if paths else 0}
+
+
+def check_range_complete(plan, n_read):
+    """Blank lines between records are legal FASTQ for the whole-file reader but shift the line arithmetic of plan_ranges: the ranks
+    together then hold fewer records than lines / 4, which shows here on at least one rank. Loud, because R1 / R2 pairing across
+    ranks can no longer be trusted."""
+    if n_read != plan["records"]:
+        raise ValueError(f"this rank's byte range held {n_read} records where the line count promised {plan['records']}: the FASTQ input "
+                         "has blank lines or is not four lines per record; rerun with NB_RANGE_SHARDING=0 (batches dealt round-robin)")
 
 
 def _dist_setup(device_id):

@@ -95,6 +95,7 @@ struct nb_fastq {
   std::vector<char*> spare;      // recycled chunk buffers (first touch of fresh pages is the expensive part of a chunk)
   bool src_done = false, stop = false;
   std::string src_error;
+  int64_t range_left = -1;       // plain files opened with nb_fastq_open_range: bytes still to read (-1 = to the end of the file)
   // text of the current batch; [pos, end) is unconsumed. malloc-managed (no zero fill on growth)
   char* buf = nullptr;
   size_t cap = 0, pos = 0, end = 0, next_pos = 0;   // next_pos: where the indexed batch ends (pos moves there when it is packed)
@@ -132,10 +133,14 @@ struct nb_fastq {
         c.n += (size_t)got;
       }
       while (c.p && !gz && !bgzf && c.n < CHUNK_BYTES) {
-        const long got = (long)::read(fd, c.p + CHUNK_PREFIX + c.n, CHUNK_BYTES - c.n);
+        size_t want = CHUNK_BYTES - c.n;
+        if (range_left >= 0 && (int64_t)want > range_left) want = (size_t)range_left;
+        if (want == 0) break;
+        const long got = (long)::read(fd, c.p + CHUNK_PREFIX + c.n, want);
         if (got < 0) { err = "read error"; break; }
         if (got == 0) break;
         c.n += (size_t)got;
+        if (range_left >= 0) range_left -= got;
       }
       std::unique_lock<std::mutex> lk(mu);
       if (!err.empty()) { src_error = err; src_done = true; std::free(c.p); cv_data.notify_all(); return; }
@@ -326,6 +331,72 @@ int32_t nb_fastq_open(const char* path, nb_fastq** out) {
   if (!q->buf) { nb_fastq_close(q); nb::set_error("nb_fastq_open: out of memory"); return NB_ERR_INVALID; }
   q->reader = std::thread([q] { q->read_loop(); });
   *out = q; return NB_OK;
+}
+
+// A byte range [begin, end) of a PLAIN (uncompressed) FASTQ file that starts at a record boundary: what one rank of a multi-GPU job
+// reads (nimble_amd/align.py finds the boundaries with nb_file_count_newlines / nb_file_nth_newline). Compressed files cannot be
+// entered in the middle: NB_ERR_UNSUPPORTED (the caller deals batches round-robin instead).
+int32_t nb_fastq_open_range(const char* path, int64_t begin, int64_t end, nb_fastq** out) {
+  if (!path || !out || begin < 0 || (end >= 0 && end < begin)) { nb::set_error("nb_fastq_open_range: bad arguments"); return NB_ERR_INVALID; }
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) { nb::set_error(std::string("nb_fastq_open_range: cannot open ") + path); return NB_ERR_INVALID; }
+  unsigned char magic[2] = {0, 0};
+  if ((long)::pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+    ::close(fd); nb::set_error("nb_fastq_open_range: compressed input cannot be read from the middle"); return NB_ERR_UNSUPPORTED;
+  }
+  if (::lseek(fd, (off_t)begin, SEEK_SET) < 0) { ::close(fd); nb::set_error("nb_fastq_open_range: seek failed"); return NB_ERR_INVALID; }
+  nb_fastq* q = new nb_fastq();
+  q->fd = fd;
+  q->range_left = end < 0 ? -1 : end - begin;
+  q->cap = (size_t)1 << 24;
+  q->buf = (char*)std::malloc(q->cap);
+  if (!q->buf) { nb_fastq_close(q); nb::set_error("nb_fastq_open_range: out of memory"); return NB_ERR_INVALID; }
+  q->reader = std::thread([q] { q->read_loop(); });
+  *out = q; return NB_OK;
+}
+
+// newlines in [begin, end) of a file (end < 0: to the end); *last_byte_out (may be NULL) = the last byte of that range, or -1 if it is empty
+int32_t nb_file_count_newlines(const char* path, int64_t begin, int64_t end, int64_t* count_out, int32_t* last_byte_out) {
+  if (!path || !count_out || begin < 0) { nb::set_error("nb_file_count_newlines: bad arguments"); return NB_ERR_INVALID; }
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) { nb::set_error(std::string("nb_file_count_newlines: cannot open ") + path); return NB_ERR_INVALID; }
+  std::vector<char> buf((size_t)1 << 22);
+  int64_t pos = begin, n = 0; int last = -1;
+  for (;;) {
+    size_t want = buf.size();
+    if (end >= 0) { if (pos >= end) break; if ((int64_t)want > end - pos) want = (size_t)(end - pos); }
+    const long got = (long)::pread(fd, buf.data(), want, (off_t)pos);
+    if (got < 0) { ::close(fd); nb::set_error("nb_file_count_newlines: read error"); return NB_ERR_INVALID; }
+    if (got == 0) break;
+    const char* p = buf.data(); const char* e = p + got;
+    while ((p = (const char*)std::memchr(p, '\n', (size_t)(e - p))) != nullptr) { ++n; ++p; }
+    last = (unsigned char)buf[(size_t)got - 1];
+    pos += got;
+  }
+  ::close(fd);
+  *count_out = n; if (last_byte_out) *last_byte_out = last;
+  return NB_OK;
+}
+
+// offset of the byte after the n-th newline (n >= 1) at or after `begin`; -1 in *offset_out if the file has fewer
+int32_t nb_file_nth_newline(const char* path, int64_t begin, int64_t n, int64_t* offset_out) {
+  if (!path || !offset_out || begin < 0 || n < 1) { nb::set_error("nb_file_nth_newline: bad arguments"); return NB_ERR_INVALID; }
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) { nb::set_error(std::string("nb_file_nth_newline: cannot open ") + path); return NB_ERR_INVALID; }
+  std::vector<char> buf((size_t)1 << 22);
+  int64_t pos = begin, seen = 0; *offset_out = -1;
+  for (;;) {
+    const long got = (long)::pread(fd, buf.data(), buf.size(), (off_t)pos);
+    if (got <= 0) break;
+    const char* p = buf.data(); const char* e = p + got;
+    while ((p = (const char*)std::memchr(p, '\n', (size_t)(e - p))) != nullptr) {
+      ++p;
+      if (++seen == n) { *offset_out = pos + (p - buf.data()); ::close(fd); return NB_OK; }
+    }
+    pos += got;
+  }
+  ::close(fd);
+  return NB_OK;
 }
 
 int32_t nb_fastq_close(nb_fastq* q) {

@@ -286,8 +286,10 @@ def test_bam_pairs_in_any_record_order_and_orphans(built, tmp_path):
 
 def test_two_ranks_equal_one_rank(built, tmp_path):
     """`align --devices 0,0`: two processes (ranks sharing this box's one GPU, gloo for the collectives; on a multi-GPU node
-    `--devices 0,1` runs the same code over RCCL), batches dealt round-robin, end-of-job merge of nimble_amd/merge.py: the bulk
-    table, the per-read table (.gz) and the fused per-cell counts must be byte-identical to the single-process run."""
+    `--devices 0,1` runs the same code over RCCL), end-of-job merge of nimble_amd/merge.py: the bulk table, the per-read table (.gz)
+    and the fused per-cell counts must equal the single-process run. Twice: each rank parsing its own byte range of the FASTQ files
+    (the default for plain FASTQ: same rows in the same order, the gzip members differ because the batches do) and batches dealt
+    round-robin (NB_RANGE_SHARDING=0, what compressed input gets: byte-identical files)."""
     import subprocess
     import sys
     lib_path, names, seqs, strs, lineage = make_library(tmp_path)
@@ -303,7 +305,7 @@ def test_two_ranks_equal_one_rank(built, tmp_path):
     write_fastq(tmp_path / "R2.fastq", [f"q{i}" for i in range(n)], r2)
     env = dict(os.environ, NB_BATCH_READS="1000", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-    def run(tag, extra):
+    def run(tag, extra, env=env):
         bulk = [sys.executable, "-m", "nimble_amd", "align", "--reference", str(lib_path), "--output", str(tmp_path / f"{tag}_bulk.tsv"),
                 "--input", str(tmp_path / "R2.fastq")] + extra
         tenx = [sys.executable, "-m", "nimble_amd", "align", "--reference", str(lib_path), "--output", str(tmp_path / f"{tag}_reads.tsv.gz"),
@@ -313,9 +315,11 @@ def test_two_ranks_equal_one_rank(built, tmp_path):
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     run("one", [])
-    run("two", ["--devices", "0,0"])
+    run("two", ["--devices", "0,0"], dict(env, NB_RANGE_SHARDING="0"))
+    run("rng", ["--devices", "0,0"])
     for name in ("bulk.tsv", "reads.tsv.gz", "cells.tsv"):
-        a, b = open(tmp_path / f"one_{name}", "rb").read(), open(tmp_path / f"two_{name}", "rb").read()
+        a, b, c = (open(tmp_path / f"{tag}_{name}", "rb").read() for tag in ("one", "two", "rng"))
         assert a == b and len(a) > 500, name
+        assert (gzip.decompress(a) == gzip.decompress(c)) if name.endswith(".gz") else a == c, name
     assert len(gzip.open(tmp_path / "two_reads.tsv.gz", "rt").read().splitlines()) > 5000
     assert not [f for f in os.listdir(tmp_path) if f.endswith(".part")]
