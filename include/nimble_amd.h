@@ -29,7 +29,7 @@ extern "C" {
 #define NB_ERR_OVERFLOW (-4)    /* class table full: raise max_classes */
 #define NB_ERR_NOGPU (-5)       /* no usable HIP device */
 
-#define NB_ABI_VERSION 2
+#define NB_ABI_VERSION 3
 #define NB_MAX_K 31
 #define NB_MAX_POSITIONS 320    /* k-mer positions per read the kernels handle (5 wave-rounds of 64) */
 #define NB_NO_CLASS 0xFFFFFFFFu
@@ -73,6 +73,7 @@ typedef struct nb_index_stats_t {
   int64_t device_bytes;   /* bytes the index occupies in HBM once uploaded */
   int64_t ph_table_bytes; /* perfect-hash table of the lane-per-read kernels (16-byte entries; 0 = not built) and its first level,  */
   int64_t ph_pilot_bytes; /* one byte per group, which the kernels stage in LDS (csrc/nb_internal.h, PHEntry)                    */
+  int64_t anchor_bytes;   /* anchor structures of the anchor-extend kernel: library text, anchor entries, sparse AND table (0 = not built) */
   int32_t k;
   int32_t uploaded;
   int32_t compact;        /* 1: compact cuckoo table (csrc/nb_internal.h), 0: wide table */
@@ -112,6 +113,11 @@ int32_t nb_index_stats(const nb_index* index, nb_index_stats_t* out);
  * (words_per_row u64), 0 if absent, <0 on error. Used by index-parity tests. */
 int32_t nb_index_query(const nb_index* index, const char* kmer_ascii, uint8_t* lext, uint8_t* rext, uint8_t* r_internal,
                        uint8_t* l_internal, uint64_t* colour_bits);
+/* host query of the anchor structures (csrc/nb_internal.h, AEntry) for one stranded k-mer: returns 1 and fills the text position of its
+ * anchor occurrence, `room` (steps the walk may take along the text from there) and, in colour_and (words_per_row u64, original sequence
+ * numbering), the AND of the classes of the k-mers at text positions [tpos, tpos + min(run, room)]; 0 if the k-mer is absent on this strand,
+ * occurs on both strands or the index has no anchor structures. Used by index-parity tests. */
+int32_t nb_index_anchor_query(const nb_index* index, const char* kmer_ascii, int32_t run, int64_t* tpos, int32_t* room, uint64_t* colour_and);
 /* copy the index into HBM of ctx's GPU and bind it to ctx */
 int32_t nb_index_upload(nb_ctx* ctx, nb_index* index);
 

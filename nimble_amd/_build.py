@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnimble_amd.so")
-SOURCES = ["nb_kernels.hip", "nb_lane.hip", "nb_index.cpp", "nb_ingest.cpp", "nb_inflate.cpp", "nb_report.cpp", "nb_host.cpp", "nb_bam.cpp"]
+SOURCES = ["nb_kernels.hip", "nb_lane.hip", "nb_anchor.hip", "nb_index.cpp", "nb_ingest.cpp", "nb_inflate.cpp", "nb_report.cpp", "nb_host.cpp", "nb_bam.cpp"]
 HEADERS = [os.path.join(CSRC, "nb_internal.h"), os.path.join(CSRC, "nb_inflate.h"), os.path.join(CSRC, "nb_wave.h"), os.path.join(CSRC, "nb_device.h"), os.path.join(REPO_ROOT, "include", "nimble_amd.h")]
 
 

@@ -31,7 +31,7 @@ class NbConfig(ct.Structure):
 class NbIndexStats(ct.Structure):
     _fields_ = [
         ("n_seqs", ct.c_int64), ("n_kmers", ct.c_int64), ("n_canonical", ct.c_int64), ("table_slots", ct.c_int64), ("table_bytes", ct.c_int64),
-        ("n_colours", ct.c_int64), ("words_per_row", ct.c_int64), ("device_bytes", ct.c_int64), ("ph_table_bytes", ct.c_int64), ("ph_pilot_bytes", ct.c_int64),
+        ("n_colours", ct.c_int64), ("words_per_row", ct.c_int64), ("device_bytes", ct.c_int64), ("ph_table_bytes", ct.c_int64), ("ph_pilot_bytes", ct.c_int64), ("anchor_bytes", ct.c_int64),
         ("k", ct.c_int32), ("uploaded", ct.c_int32), ("compact", ct.c_int32), ("words_internal", ct.c_int32),
     ]
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "nb_index_destroy": (ct.c_int32, [ct.c_void_p]),
     "nb_index_stats": (ct.c_int32, [ct.c_void_p, ct.POINTER(NbIndexStats)]),
     "nb_index_query": (ct.c_int32, [ct.c_void_p, ct.c_char_p, c_u8p, c_u8p, c_u8p, c_u8p, c_u64p]),
+    "nb_index_anchor_query": (ct.c_int32, [ct.c_void_p, ct.c_char_p, ct.c_int32, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int32), c_u64p]),
     "nb_index_upload": (ct.c_int32, [ct.c_void_p, ct.c_void_p]),
     "nb_packed_stride_words": (ct.c_int64, [ct.c_int32]),
     "nb_pack_reads": (ct.c_int32, [ct.c_char_p, c_i64p, ct.c_int64, ct.c_int32, c_u64p, c_u16p]),

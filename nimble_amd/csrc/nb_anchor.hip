@@ -1,0 +1,314 @@
+// nb_anchor.hip — the anchor-extend kernel: one read per lane like nb_lane.hip, but the walk of docs/SPEC.md §3 follows the library TEXT.
+//
+// nb_lane.hip looks every k-mer position of a read up (131 table requests and ~380 wave-instructions per 150-bp read: it runs at the
+// request rate of the memory system AND at the issue rate of the SIMDs at once, profiles/r02_tuning_notes.md §4). Fewer requests and fewer
+// instructions per read need fewer POSITIONS handled one by one. Here a table hit names a text position (AEntry, nb_internal.h); from there
+// the read is compared with the text 32 bases at a time, every matching base is one step of the walk (right extension by construction),
+// and the AND of the classes of the k-mers passed comes from the sparse table with two loads. A lookup happens only where the read leaves
+// its anchor sequence or where the walk has to seed:
+//
+//   round     every lane holds one pending lookup: SEEK (seed scan, stride 3) or STEP (the k-mer that ends at the base where the last run
+//             stopped: the walk goes on iff it is in the table on the stream strand and the base before it is one of its left extensions —
+//             the same (K+1)-mer test as nb_lane.hip). A successful lookup is followed by the run along the text.
+//   other     SPEC §4 needs the coverage of the OTHER orientation too. It is zero unless one of that orientation's seed-scan positions
+//   strand    (stream positions p = last, last - 3, ...) hits on the opposite strand. Positions inside verified runs cannot (runs never
+//             enter k-mers that occur on both strands); the remaining ones are looked up after the walk, four in flight per lane.
+//   redo      anything else — a k-mer on both strands, any opposite-strand hit, a first seed at or beyond L/5 (left extension), a class
+//             wider than one word — puts the read on the redo list of the wave-per-read kernel, exactly like nb_lane.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "nb_device.h"
+
+namespace nb {
+
+struct AnchorHead {
+  const AEntry* table; const uint8_t* pilots; PHash ph; int K;
+  const uint32_t* text; const uint64_t* sparse; long long T;
+  const uint64_t* reads; const uint16_t* lens; int max_len, stride, nwb;
+  long long n;
+  int pilot_lds_bytes, rec_dwords;                   // dynamic LDS: [pilots][per wave: rec_dwords x 64 dwords]
+};
+
+struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+
+template <int NR>
+__global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  uint8_t* s_pilots = s_dyn;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wpb = (int)(blockDim.x >> 6);
+  uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;   // dword j of this lane's record at rec[j * 64 + lane]
+  if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
+    *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
+  __syncthreads();
+  const long long nwaves = (long long)gridDim.x * wpb;
+  const int K = h.K;
+  const uint64_t kmask = (1ull << (2 * K)) - 1;
+  const uint32_t nkmask = (1u << K) - 1u;
+  const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1;
+  constexpr uint32_t F_SEEDED = 1u, F_STARTED = 2u, F_SLOW = 4u, F_HARD = 8u, F_OPP = 16u, F_LEXT = 32u, F_ERR = 64u;
+
+  for (long long base = ((long long)blockIdx.x * wpb + wave) * 64; base < h.n; base += nwaves * 64) {
+    const long long idx = base + lane;
+    const bool active = idx < h.n;
+    const uint32_t r = active ? (uint32_t)idx : 0u;
+    int L = 0;
+    if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
+    {   // stage the record (this lane's column of LDS)
+      const uint64_t* __restrict__ rp = h.reads + (size_t)r * h.stride;
+      for (int j = 0; j < nwb + nwn; ++j) {
+        const uint64_t w = active ? rp[j] : 0ull;
+        rec[(2 * j) * 64 + lane] = (uint32_t)w; rec[(2 * j + 1) * 64 + lane] = (uint32_t)(w >> 32);
+      }
+      rec[(2 * (nwb + nwn)) * 64 + lane] = 0u; rec[(2 * (nwb + nwn) + 1) * 64 + lane] = 0u;
+    }
+    const int last = L - K;
+    bool rcf = false;                            // stream = reverse complement of the read
+    uint32_t fl = 0;
+
+    // 16 bases of the stream from stream position q (2 bits each, first base at bit 0) and their N-or-beyond-the-read bits
+    auto get16 = [&](int q, uint32_t& win, uint32_t& nwin) {
+      int hi = L - 1 - q; hi = hi < 0 ? 0 : hi;                        // reverse lanes: the 16 bases ENDING at read base hi, reversed and complemented
+      const int jf = q >> 4, jr = hi >> 4, jr1 = jr > 0 ? jr - 1 : 0;
+      const uint32_t A = rec[(rcf ? jr : jf + 1) * 64 + lane], B = rec[(rcf ? jr1 : jf) * 64 + lane];
+      uint32_t w = (uint32_t)((((uint64_t)A << 32) | B) >> (rcf ? 2 * ((hi & 15) + 1) : 2 * (q & 15)));
+      uint32_t rev = __brev(w); rev = ((rev & 0x55555555u) << 1) | ((rev >> 1) & 0x55555555u);
+      win = rcf ? ~rev : w;
+      const int nb0 = 2 * nwb, nf = q >> 5, nr_ = hi >> 5, nr1 = nr_ > 0 ? nr_ - 1 : 0;
+      const uint32_t NA = rec[(nb0 + (rcf ? nr_ : nf + 1)) * 64 + lane], NB = rec[(nb0 + (rcf ? nr1 : nf)) * 64 + lane];
+      uint32_t nw = (uint32_t)((((uint64_t)NA << 32) | NB) >> (rcf ? (hi & 31) + 17 : (q & 31))) & 0xFFFFu;
+      nw = rcf ? (__brev(nw) >> 16) : nw;
+      const int left = L - q;                                          // stream positions of this window that lie inside the read
+      nw |= left >= 16 ? 0u : (left <= 0 ? 0xFFFFu : ((0xFFFFu << left) & 0xFFFFu));
+      nwin = nw;
+    };
+    // 32 bases from stream position q
+    auto get32 = [&](int q, uint64_t& win, uint32_t& nwin) {
+      uint32_t w0, n0, w1, n1; get16(q, w0, n0); get16(q + 16, w1, n1);
+      win = ((uint64_t)w1 << 32) | w0; nwin = (n1 << 16) | n0;
+    };
+    // one table lookup: canonical k-mer -> slot (pilot from LDS) -> entry
+    struct Look { uint4 e; uint32_t want; bool o; };
+    auto lookup = [&](uint64_t x, bool valid) {
+      const uint64_t y = rc_kmer(x, K);
+      Look k; k.o = x > y;
+      const PHProbe pr = ph_probe(k.o ? y : x, h.ph);
+      k.want = pr.want;
+      k.e = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_slot(pr, (uint32_t)s_pilots[pr.group], h.ph) : 0u]);
+      return k;
+    };
+
+    // ---- orientation: which strand do the k-mers at the start, the middle and the end of the read hit? ----
+    if (last >= 0) {
+      int votes = 0;
+      Look pk[3]; bool pv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int p = u == 0 ? 0 : (u == 1 ? last >> 1 : last);
+        uint64_t w; uint32_t nn; get32(p, w, nn);
+        pv[u] = (nn & nkmask) == 0;
+        pk[u] = lookup(w & kmask, pv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const uint32_t d = pk[u].e.x ^ pk[u].want;
+        if (pv[u] && d < 4u && !(d & 2u)) votes += ((d & 1u) == (pk[u].o ? 1u : 0u)) ? 1 : -1;
+      }
+      rcf = votes < 0;
+    }
+
+    // ---- the walk, in rounds: one lookup per lane and round, followed by the run along the text if it succeeds ----
+    int mode = (active && last >= 0) ? 0 : 2;   // 0 = SEEK a seed at `pos` (stride 3), 1 = STEP over stream base `pos`, 2 = done
+    int pos = 0, cov = 0;
+    uint32_t lo = 0; uint64_t a0 = 0;
+    Mask<NR> cover;                             // positions whose status on BOTH strands is known: looked up, or inside a verified run
+#pragma unroll
+    for (int wi = 0; wi < NR; ++wi) cover.w[wi] = 0;
+    const int L5 = L / 5;
+    int rounds = 0;
+    while (__ballot(mode != 2)) {
+      const bool act = mode != 2;
+      const bool step = mode == 1;
+      const int q = act ? (step ? pos - K + 1 : pos) : 0;             // k-mer position of this round's lookup
+      uint64_t w; uint32_t nn; get32(q - (step ? 1 : 0), w, nn);      // (STEP: one base earlier, for the left-extension test; q >= 1 there)
+      const uint32_t pb = (uint32_t)w & 3u;
+      const uint64_t x = (step ? (w >> 2) : w) & kmask;
+      const bool valid = act && (((step ? (nn >> 1) : nn) & nkmask) == 0);
+      const Look k = lookup(x, valid);
+      const uint32_t d = k.e.x ^ k.want, pay = k.e.y;
+      const bool found = valid && d < 4u, both = found && (d & 2u);
+      const bool hS = found && !both && ((d & 1u) == (k.o ? 1u : 0u));
+      fl |= (both ? F_HARD : 0u) | ((found && !both && !hS) ? F_OPP : 0u);
+      const bool ok = hS && (!step || ((pay >> (4u + pb)) & 1u));
+      // the run: compare the stream from base q + K with the text from tpos + K, 32 bases per step, at most `room` steps
+      const uint32_t tpos = k.e.z;
+      int steps = 0;
+      const int b0 = q + K;
+      int maxsteps = 0;
+      if (ok) { maxsteps = (int)(k.e.w & 0xFFFFu); const int rem = L - b0; maxsteps = maxsteps < rem ? maxsteps : rem; }
+      bool ext = maxsteps > 0;
+      while (__ballot(ext)) {
+        if (ext) {
+          uint64_t sw; uint32_t sn; get32(b0 + steps, sw, sn);
+          const uint32_t tb = tpos + (uint32_t)(K + steps);
+          const U3 tw3 = *reinterpret_cast<const U3*>(h.text + (tb >> 4));
+          const uint32_t sh = 2u * (tb & 15u);
+          const uint64_t t01 = ((uint64_t)tw3.b << 32) | tw3.a;
+          const uint64_t tw = sh ? ((t01 >> sh) | ((uint64_t)tw3.c << (64u - sh))) : t01;
+          const uint64_t df = sw ^ tw;
+          const uint64_t m2 = (df | (df >> 1)) & 0x5555555555555555ull;
+          const int fm = m2 ? (__builtin_ctzll(m2) >> 1) : 32;
+          const int fn = sn ? __builtin_ctz(sn) : 32;
+          const int m = fm < fn ? fm : fn;
+          const int room_left = maxsteps - steps;
+          const int take = m < room_left ? m : room_left;
+          steps += take;
+          ext = (m == 32) && steps < maxsteps;
+        }
+      }
+      if (ok) {
+        if (!step && !(fl & F_SEEDED) && q >= L5 && q > 0) fl |= F_LEXT;      // the first seed may have a left extension: wave-per-read kernel
+        cov += (step ? 1 : K) + steps;
+        const uint32_t n = (uint32_t)steps + 1u;
+        const int lv = 31 - __builtin_clz(n);
+        const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + tpos;
+        const uint64_t v = sp[0] & sp[n - (1u << lv)];
+        const uint32_t w0 = pay >> 11;
+        const bool first = !(fl & F_STARTED);
+        a0 = first ? v : ((w0 == lo) ? (a0 & v) : 0ull);
+        lo = first ? w0 : lo;
+        fl |= F_SEEDED | F_STARTED | ((pay & (1u << 10)) ? F_SLOW : 0u);
+        set_range<NR>(cover, q, q + steps);
+        pos = b0 + steps;                                                     // the base the run stopped at
+        mode = pos >= L ? 2 : 1;
+      } else if (act) {
+        if (valid) set_range<NR>(cover, q, q);
+        if (step) mode = pos > last ? 2 : 0;                                  // the walk broke at base pos: seed scan from there (SPEC §3)
+        else { pos += 3; mode = pos > last ? 2 : 0; }
+      }
+      if (++rounds > 4 * h.max_len + 8) { fl |= act ? F_ERR : 0u; mode = 2; }  // (cannot happen: every two rounds advance pos; an exit every wave reaches)
+    }
+
+    // ---- the other orientation: does any of ITS seed-scan positions hit? (stream positions p = last, last - 3, ... not yet known) ----
+    {
+      Mask<NR> todo;
+      const uint64_t PAT = 0x9249249249249249ull;
+      const bool need = active && last >= 0 && !(fl & (F_HARD | F_OPP | F_LEXT | F_SLOW | F_ERR));
+#pragma unroll
+      for (int wi = 0; wi < NR; ++wi) {
+        const int res = ((last % 3) - (wi % 3) + 3) % 3;
+        uint64_t m = (PAT << res) & ~cover.w[wi];
+        const int top = last - wi * 64;                                       // positions <= last only
+        m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
+        todo.w[wi] = need ? m : 0ull;
+      }
+      while (__ballot(any_set<NR>(todo))) {
+        Look kk[4]; bool vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int p = -1;
+#pragma unroll
+          for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
+          uint64_t w; uint32_t nn; get32(p < 0 ? 0 : p, w, nn);
+          vv[u] = p >= 0 && (nn & nkmask) == 0;
+          kk[u] = lookup(w & kmask, vv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t d = kk[u].e.x ^ kk[u].want;
+          const bool found = vv[u] && d < 4u;
+          const bool mine = found && !(d & 2u) && ((d & 1u) == (kk[u].o ? 1u : 0u));
+          if (found && !mine) { fl |= F_OPP; }
+        }
+        if (fl & F_OPP) {
+#pragma unroll
+          for (int wi = 0; wi < NR; ++wi) todo.w[wi] = 0;
+        }
+      }
+    }
+
+    // ---- SPEC §4 per lane, outputs, redo list ----
+    asm volatile("" ::: "memory");
+    const LaneTail& T = *tp;
+    const BatchArgs& a = T.a;
+    const int pmin = a.lens ? (int)a.pct_min[L] : a.pct_fixed;
+    int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0;
+    uint32_t cls = NB_NO_CLASS;
+    bool to_redo = false, final_ = false, call = false;
+    if (active && L >= K) {
+      if (fl & (F_HARD | F_OPP | F_LEXT | F_SLOW | F_ERR)) to_redo = true;
+      else {
+        final_ = true;                                                        // the other orientation has no hit: its coverage is 0 (NO_HIT)
+        if (a.out_cov) a.out_cov[r] = rcf ? ((uint64_t)(cov & 0xFFFF) << 16) : (uint64_t)(cov & 0xFFFF);
+        const int cheapS = cheap_reason_p(cov, pmin, a);
+        const uint32_t n = (uint32_t)__popcll(a0);
+        int rs = 0;
+        if (cheapS != 0) rs = cheapS;
+        else if (n == 0) rs = NB_EMPTY_EQCLASS;
+        else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
+        else if ((rcf && a.strand_filter == NB_STRAND_FIVEPRIME) || (!rcf && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
+        if (rs) reason = rs;
+        else { score = cov; orient = rcf ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
+      }
+    } else if (active) { final_ = true; if (a.out_cov) a.out_cov[r] = 0ull; }
+    cls = intern_lane(T.ct, T.W, call, lo, a0);
+    if (call && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], 1ull);
+    if (active && final_) {
+      atomicAdd(&s_reason[reason], 1u);
+      if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
+      if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
+    }
+    {
+      const uint64_t mredo = __ballot(to_redo);
+      if (mredo) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        if (to_redo) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+}
+
+template <int NR>
+static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
+  const long long need = (h.n + 64LL * waves - 1) / (64LL * waves);
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL((nb_anchor_kernel<NR>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
+  NB_HIP(hipGetLastError());
+  return NB_OK;
+}
+
+int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
+  int waves = 0;
+  const int64_t lds = lane_lds_bytes(c, a.max_len, &waves);
+  if (lds <= 0 || !c->has_anchor) { set_error("launch_anchor: shape does not fit"); return NB_ERR_UNSUPPORTED; }
+  NB_HIP(hipMemsetAsync(ll.counters, 0, 8, s));
+  if (!c->d_lane_tail) NB_HIP(hipMalloc((void**)&c->d_lane_tail, sizeof(LaneTail)));
+  LaneTail t{c->ct, a, ll, ix.W};
+  NB_HIP(hipMemcpyAsync(c->d_lane_tail, &t, sizeof t, hipMemcpyHostToDevice, s));
+  const int nwn = (a.nwb + 1) >> 1;
+  AnchorHead h{c->d_atable, c->d_ph_pilots, c->ph, ix.K, c->d_text, c->d_sparse, c->text_len, a.reads, a.lens, a.max_len, a.stride, a.nwb, a.n,
+               (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16), 2 * (a.nwb + nwn) + 2};
+  const LaneTail* dt = (const LaneTail*)c->d_lane_tail;
+  switch (nr) {
+    case 1: return launch_anchor_t<1>(c, h, dt, waves, lds, s);
+    case 2: return launch_anchor_t<2>(c, h, dt, waves, lds, s);
+    case 3: return launch_anchor_t<3>(c, h, dt, waves, lds, s);
+    case 4: return launch_anchor_t<4>(c, h, dt, waves, lds, s);
+    default: return launch_anchor_t<5>(c, h, dt, waves, lds, s);
+  }
+}
+
+}  // namespace nb

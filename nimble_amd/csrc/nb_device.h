@@ -258,10 +258,69 @@ struct LaneLists {
   uint32_t* redo_list;    // reads for the wave-per-read kernel
   uint32_t* counters;     // [0] = entries in rc_list, [1] = entries in redo_list
 };
+// everything the tail of a lane-per-read batch needs (class table, outputs, filters, lists): read from device memory at the point of use
+struct LaneTail { DevClasses ct; BatchArgs a; LaneLists ll; int W; };
+
+#if defined(__HIPCC__)
+// per-lane interning of a one-word set {word index lo, bits a0} in the shared class table; returns the class id or NB_NO_CLASS.
+// Same table protocol as intern_class (nb_kernels.hip): key = content hash, full-content verification through (spans, word).
+__device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, bool want, uint32_t lo, uint64_t a0) {
+  const uint64_t hx = mix64(a0 ^ (0x9E3779B97F4A7C15ull * (uint64_t)(lo + 1u)));
+  const uint64_t key = hx ? hx : 1ull;
+  const uint64_t smask = (1ull << ct.cap_log2) - 1;
+  uint64_t h = (key * HASH_MULT) >> (64 - ct.cap_log2);
+  uint32_t result = NB_NO_CLASS;
+  uint64_t probes = 0;                              // slots passed: the table is full once every slot was seen (intern_class has the same bound)
+  bool pending = want;
+  for (uint32_t it = 0; it < (1u << 24) && __ballot(pending); ++it) {
+    if (pending) {
+      const uint64_t cur = __hip_atomic_load(&ct.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == 0) {
+        unsigned long long expected = 0ull;
+        __hip_atomic_compare_exchange_strong(&ct.keys[h], &expected, (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (expected == 0ull) {                       // this lane owns the slot: allocate, write the row, publish
+          const uint32_t id = __hip_atomic_fetch_add(ct.n_classes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (id >= ct.max_classes) {
+            atomicOr(ct.err, 1u);
+            __hip_atomic_store(&ct.ids[h], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending = false;
+          } else {
+            for (int w = 0; w < W; ++w)
+              __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)((uint32_t)w == lo ? a0 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ct.spans[id], lo | (lo << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&ct.ids[h], id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            result = id; pending = false;
+          }
+        }
+        // lost the race: look at the same slot again in the next iteration (its key is set now)
+      } else if (cur == key) {
+        const uint32_t idp = __hip_atomic_load(&ct.ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (idp == 0xFFFFFFFFu) pending = false;      // table overflow recorded by the owner
+        else if (idp != 0u) {
+          const uint32_t id = idp - 1u;
+          const uint32_t sp = __hip_atomic_load(&ct.spans[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t word = __hip_atomic_load(&ct.rows[(size_t)id * W + lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (sp == (lo | (lo << 16)) && word == a0) { result = id; pending = false; }
+          else { h = (h + 1) & smask; ++probes; }     // a different set with the same 64-bit hash: keep probing
+        }
+        // idp == 0: the owner is still publishing: poll again in the next iteration
+      } else { h = (h + 1) & smask; ++probes; }
+      if (probes > smask) { atomicOr(ct.err, 1u); pending = false; }
+    }
+  }
+  if (pending) atomicOr(ct.err, 2u);
+  return result;
+}
+
+#endif
 }  // namespace nb
 
 struct nb_ctx;
 namespace nb {
+// nb_anchor.hip: the anchor-extend kernel (one launch; what it cannot finish exactly goes on ll.redo_list like the lane path's)
+int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
 // nb_lane.hip: both lane-per-read passes of one batch, then gather of the redo reads; nb_lane_scatter puts their results back
 int launch_lane(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
 int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block);   // 0 = the lane path does not fit this shape
@@ -284,6 +343,7 @@ struct nb_ctx {
   uint64_t* d_redo_reads = nullptr; int64_t redo_words_cap = 0; uint16_t* d_redo_lens = nullptr; uint32_t* d_redo_out = nullptr;   // gathered redo reads + their results (4 u32 per read)
   void* d_lane_tail = nullptr;     // LaneTail of the current batch (nb_lane.hip)
   nb::PHEntry* d_ph_table = nullptr; uint8_t* d_ph_pilots = nullptr; nb::PHash ph{}; bool has_ph = false;   // perfect-hash table of the lane kernels
+  nb::AEntry* d_atable = nullptr; uint32_t* d_text = nullptr; uint64_t* d_sparse = nullptr; long long text_len = 0; bool has_anchor = false;   // anchor structures (nb_anchor.hip)
   std::string last_kernels;        // kernels launched by the last nb_align_batch (nb_last_kernel_names)   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
   // score_percent table
   uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0; std::vector<uint16_t> pct_host;

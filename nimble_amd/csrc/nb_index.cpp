@@ -368,6 +368,70 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         ix->has_ph = true; ix->ph = h; ix->ph_table.swap(tab); ix->ph_pilots.swap(pilots);
       }
     }
+
+    // 5c. anchor structures of the anchor-extend kernel (nb_internal.h): text, per-k-mer anchor (first occurrence) + room, sparse AND table
+    const char* an_env = std::getenv("NB_ANCHOR");
+    int64_t T = 0;
+    for (int s = 0; s < n_seqs; ++s) T += lens[s];
+    if (ix->has_ph && !(an_env && an_env[0] == '0') && T < ANCHOR_MAX_TEXT) {
+      std::vector<uint8_t> code((size_t)T);
+      std::vector<uint32_t> vrun((size_t)T + 1, 0);          // valid bases from j to the end of its sequence / the next N
+      { int64_t j0 = 0;
+        for (int s = 0; s < n_seqs; ++s) {
+          for (int64_t i = 0; i < lens[s]; ++i) code[(size_t)(j0 + i)] = (uint8_t)code_of(seqs[s][i]);
+          uint32_t run = 0;
+          for (int64_t i = lens[s] - 1; i >= 0; --i) { run = code[(size_t)(j0 + i)] == 4 ? 0u : run + 1u; vrun[(size_t)(j0 + i)] = run; }
+          j0 += lens[s];
+        } }
+      ix->text_len = T;
+      ix->text.assign((size_t)((T + 15) / 16 + 4), 0u);
+      for (int64_t j = 0; j < T; ++j) if (code[(size_t)j] < 4) ix->text[(size_t)(j >> 4)] |= (uint32_t)code[(size_t)j] << (2 * (j & 15));
+      // canonical entry (index into canons) and strand flag of the k-mer that starts at every text position
+      constexpr uint32_t NONE = 0xFFFFFFFFu;
+      std::vector<uint32_t> cidx((size_t)T, NONE);
+      parallel_ranges((size_t)T, threads, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+          if (vrun[j] < (uint32_t)k) continue;
+          uint64_t x = 0;
+          for (int t = 0; t < k; ++t) x |= (uint64_t)code[j + (size_t)t] << (2 * t);
+          const uint64_t y = rc_kmer_host(x, k), canon = std::min(x, y);
+          auto it = std::lower_bound(canons.begin(), canons.end(), canon, [](const Canon& c, uint64_t v) { return c.key < v; });
+          cidx[j] = (uint32_t)(it - canons.begin());             // (every library k-mer is in canons)
+        }
+      });
+      std::vector<uint32_t> tpos_of((size_t)n_canon, NONE);
+      for (int64_t j = 0; j < T; ++j) { const uint32_t i = cidx[(size_t)j]; if (i != NONE && tpos_of[i] == NONE) tpos_of[i] = (uint32_t)j; }
+      auto is_both = [&](uint32_t i) { return canons[i].pay[0] != PAY_ABSENT && canons[i].pay[1] != PAY_ABSENT; };
+      std::vector<uint8_t> room((size_t)T + 1, 0);
+      for (int64_t j = T - 2; j >= 0; --j) {
+        const uint32_t a = cidx[(size_t)j], b = cidx[(size_t)j + 1];
+        room[(size_t)j] = (a != NONE && b != NONE && !is_both(b)) ? (uint8_t)std::min<uint32_t>((uint32_t)room[(size_t)j + 1] + 1u, ANCHOR_MAX_ROOM) : (uint8_t)0;
+      }
+      ix->sparse.assign((size_t)ANCHOR_LEVELS * (size_t)T, 0ull);
+      for (int64_t j = 0; j < T; ++j) {
+        const uint32_t i = cidx[(size_t)j];
+        if (i == NONE) continue;
+        const Canon& cn = canons[i];
+        const uint32_t pay = cn.pay[0] != PAY_ABSENT ? cn.pay[0] : cn.pay[1];      // (both strands: never part of a run, any class will do)
+        ix->sparse[(size_t)j] = ix->desc[pay >> 10].m0;
+      }
+      for (int l = 1; l < ANCHOR_LEVELS; ++l) {
+        const uint64_t* prev = ix->sparse.data() + (size_t)(l - 1) * (size_t)T; uint64_t* cur = ix->sparse.data() + (size_t)l * (size_t)T;
+        const int64_t half = 1ll << (l - 1);
+        parallel_ranges((size_t)T, threads, [&](size_t lo, size_t hi) {
+          for (size_t j = lo; j < hi; ++j) cur[j] = ((int64_t)j + half < T) ? (prev[j] & prev[j + (size_t)half]) : 0ull;
+        });
+      }
+      ix->atable.assign(ix->ph_table.size(), AEntry{0xFFFFFFFFu, PAY_ABSENT, 0u, 0u});
+      for (int64_t i = 0; i < n_canon; ++i) {
+        const PHProbe q = ph_probe(canons[(size_t)i].key, ix->ph);
+        const uint32_t slot = ph_slot(q, ix->ph_pilots[q.group], ix->ph);
+        const PHEntry& pe = ix->ph_table[slot];
+        const uint32_t t = tpos_of[(size_t)i];
+        ix->atable[slot] = AEntry{pe.key, pe.pay, t == NONE ? 0u : t, (t == NONE || is_both((uint32_t)i)) ? 0u : (uint32_t)room[t]};
+      }
+      ix->has_anchor = true;
+    }
   } else {
   uint64_t nb64 = (uint64_t)((double)n_canon / (SLOTS_PER_BUCKET * TABLE_MAX_LOAD)) + 1;
   if (nb64 < 256) nb64 = 256;

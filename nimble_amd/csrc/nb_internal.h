@@ -143,6 +143,27 @@ NB_HD inline uint32_t ph_slot(const PHProbe& p, uint32_t pilot, const PHash& h) 
   return s >= h.n_slots ? s - h.n_slots : s;
 }
 
+// ---- ANCHOR structures of the anchor-extend kernel (nb_anchor.hip): walk a read along the library TEXT instead of looking every k-mer up ----
+// Once a k-mer of the read is known to sit at text position t (a table hit: its entry names ONE occurrence, the first in library order),
+// the next k-mers of the walk of docs/SPEC.md §3 need no lookup while the read's next bases equal the text's: the (K+1)-mer read[i..i+K]
+// then occurs in the library by construction, so the base is a right extension, the next k-mer is the text's k-mer at t + 1, and its class
+// is a property of the text position. 32 bases are compared per step (XOR of two 64-bit windows), and the AND of the classes of a run of
+// text positions [t, t + n) comes from a sparse table with two loads whatever n is (AND is idempotent: two overlapping power-of-two
+// blocks). Only where the read leaves its anchor sequence (a sequencing error, an allele difference, an N, the end of the sequence) does
+// the kernel look a k-mer up again — ~20-25 lookups per 150-bp read instead of 131.
+//   text      the library sequences concatenated, 2 bits per base, 16 bases per u32 (base j at bits [2(j & 15), +2) of word j >> 4);
+//             N is stored as A and never compared: `room` stops a run before it
+//   AEntry    same slot, key and pay as the PHEntry of the k-mer (same PHash, same pilots); tpos = text position of the anchor
+//             occurrence; room = how many times the walk may step to the NEXT text k-mer from there: the following k-mers are valid
+//             (no N, same sequence), do not occur on both strands, and the run stays below 2^ANCHOR_LEVELS positions
+//   sparse    level l, position t: AND of the class words (internal numbering, one word: only built when max_desc_nw == 1; all k-mers of
+//             a sequence lie in the word of the sequence's component) of the k-mers at text positions [t, t + 2^l); level-major
+struct AEntry { uint32_t key, pay, tpos, room; };
+static_assert(sizeof(AEntry) == 16, "anchor entry must be 16 bytes");
+constexpr int ANCHOR_LEVELS = 8;                        // runs of up to 255 k-mer positions
+constexpr uint32_t ANCHOR_MAX_ROOM = (1u << ANCHOR_LEVELS) - 2;
+constexpr int64_t ANCHOR_MAX_TEXT = 1ll << 31;
+
 // A colour (equivalence class of the graph) for the wave-per-read kernels: the span of u64 words of its bitset that can be non-zero, with
 // the first two words inline (32 bytes, two dwordx4 issued together). Bit positions are INTERNAL sequence numbers: the index builder
 // renumbers the sequences so that every connected component of the "share a k-mer" relation (a locus, for a gene-family library) starts
@@ -187,6 +208,11 @@ struct HostIndex {
   PHash ph{};
   std::vector<PHEntry> ph_table;      // ph.n_slots entries
   std::vector<uint8_t> ph_pilots;     // ph.n_groups bytes
+  bool has_anchor = false;            // anchor structures of nb_anchor.hip (built next to the perfect-hash table)
+  int64_t text_len = 0;               // bases in `text`
+  std::vector<uint32_t> text;         // text_len bases + 64 bases of padding
+  std::vector<AEntry> atable;         // ph.n_slots entries, slot for slot the k-mers of ph_table
+  std::vector<uint64_t> sparse;       // ANCHOR_LEVELS * text_len words
   int max_desc_nw = 1;                // widest class span in words (1 = every class inside one word: the lane-per-read kernels apply)
   std::vector<int32_t> perm;          // original sequence index -> internal bit position
   std::vector<int32_t> inv_perm;      // internal bit position -> original sequence index, -1 = padding

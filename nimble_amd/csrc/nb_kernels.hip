@@ -1145,7 +1145,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_lane_tail); (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_lane_tail); (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
 
@@ -1169,7 +1169,8 @@ int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
   s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = h.compact ? (int64_t)h.ctable.size() * 2 : (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
   s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
   s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0; s->words_internal = h.words_dev; s->ph_table_bytes = (int64_t)(h.ph_table.size() * sizeof(PHEntry)); s->ph_pilot_bytes = (int64_t)h.ph_pilots.size();
-  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size()); s->k = h.k; s->uploaded = h.uploaded;
+  s->anchor_bytes = (int64_t)(h.atable.size() * sizeof(AEntry) + h.text.size() * 4 + h.sparse.size() * 8);
+  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.text.size() * 4 + h.sparse.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
   return NB_OK;
 }
 
@@ -1219,6 +1220,34 @@ int32_t nb_index_query(const nb_index* ix, const char* kmer, uint8_t* lext, uint
   }
 }
 
+int32_t nb_index_anchor_query(const nb_index* ix, const char* kmer, int32_t run, int64_t* tpos, int32_t* room, uint64_t* colour_and) {
+  if (!ix || !kmer || run < 0) { set_error("nb_index_anchor_query: bad arguments"); return NB_ERR_INVALID; }
+  const HostIndex& h = *ix->h;
+  if (!h.has_anchor) return 0;
+  uint64_t x = 0;
+  for (int j = 0; j < h.k; ++j) {
+    int c; switch (kmer[j]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: return 0; }
+    x |= (uint64_t)c << (2 * j);
+  }
+  const uint64_t y = rc_kmer_host(x, h.k), canon = x < y ? x : y; const uint32_t o = (x != canon) ? 1u : 0u;
+  const PHProbe q = ph_probe(canon, h.ph);
+  const AEntry& e = h.atable[ph_slot(q, h.ph_pilots[q.group], h.ph)];
+  const uint32_t d = e.key ^ q.want;
+  if (d >= 4u || (d & 2u) || (d & 1u) != o) return 0;
+  if (tpos) *tpos = (int64_t)e.tpos;
+  if (room) *room = (int32_t)e.room;
+  if (colour_and) {
+    const uint32_t n = (uint32_t)std::min<int64_t>(run, (int64_t)e.room) + 1u;
+    int lv = 0; while ((2u << lv) <= n) ++lv;
+    const uint64_t* sp = h.sparse.data() + (size_t)lv * (size_t)h.text_len + e.tpos;
+    const uint64_t v = sp[0] & sp[n - (1u << lv)];
+    const uint32_t w0 = e.pay >> 11;
+    std::memset(colour_and, 0, (size_t)h.words * 8);
+    for (int b = 0; b < 64; ++b) if ((v >> b) & 1ull) { const int32_t orig = h.inv_perm[(size_t)w0 * 64 + (size_t)b]; if (orig >= 0) colour_and[orig >> 6] |= 1ull << (orig & 63); }
+  }
+  return 1;
+}
+
 int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   if (!c || !ix) { set_error("nb_index_upload: null argument"); return NB_ERR_INVALID; }
   NB_HIP(hipSetDevice(c->device));
@@ -1231,6 +1260,14 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
     NB_HIP(hipMalloc((void**)&c->d_ph_table, h.ph_table.size() * sizeof(PHEntry))); NB_HIP(hipMalloc((void**)&c->d_ph_pilots, h.ph_pilots.size()));
     NB_HIP(hipMemcpy(c->d_ph_table, h.ph_table.data(), h.ph_table.size() * sizeof(PHEntry), hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(c->d_ph_pilots, h.ph_pilots.data(), h.ph_pilots.size(), hipMemcpyHostToDevice));
+  }
+  (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr;
+  c->has_anchor = h.has_anchor; c->text_len = h.text_len;
+  if (h.has_anchor) {
+    NB_HIP(hipMalloc((void**)&c->d_atable, h.atable.size() * sizeof(AEntry))); NB_HIP(hipMalloc((void**)&c->d_text, h.text.size() * 4)); NB_HIP(hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8));
+    NB_HIP(hipMemcpy(c->d_atable, h.atable.data(), h.atable.size() * sizeof(AEntry), hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(c->d_text, h.text.data(), h.text.size() * 4, hipMemcpyHostToDevice));
+    NB_HIP(hipMemcpy(c->d_sparse, h.sparse.data(), h.sparse.size() * 8, hipMemcpyHostToDevice));
   }
   if (h.compact) {
     NB_HIP(hipMalloc((void**)&c->d_ctable, h.ctable.size() * sizeof(CBucket)));
@@ -1246,7 +1283,7 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   if (!c->d_ct) NB_HIP(hipMalloc((void**)&c->d_ct, sizeof(DevClasses)));
   NB_HIP(hipMemcpy(c->d_ct, &c->ct, sizeof(DevClasses), hipMemcpyHostToDevice));
   c->hash = h.hash; c->W = h.words_dev; c->W_ext = h.words; c->inv_perm = h.inv_perm; c->K = h.k; c->n_seqs = h.n_seqs;
-  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size()); h.uploaded = 1;
+  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.text.size() * 4 + h.sparse.size() * 8); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
 }
 
@@ -1318,8 +1355,14 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     }
     if (!c->d_list_counters) NB_HIP(hipMalloc((void**)&c->d_list_counters, 8));
     LaneLists ll{c->d_lists, c->d_lists + c->lists_cap, c->d_list_counters};
-    rc = launch_lane(c, nr, ix, a, ll, s); if (rc != NB_OK) return rc;
-    { char buf[96]; std::snprintf(buf, sizeof buf, "nb_lane_kernel<%d, 0>;nb_lane_kernel<%d, 1>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr); c->last_kernels = buf; }
+    // anchor-extend kernel (nb_anchor.hip) when the index carries the anchor structures: one launch, far fewer lookups per read
+    const char* anchor_env = std::getenv("NB_ANCHOR");
+    const bool use_anchor = c->has_anchor && !(anchor_env && anchor_env[0] == '0');
+    rc = use_anchor ? launch_anchor(c, nr, ix, a, ll, s) : launch_lane(c, nr, ix, a, ll, s); if (rc != NB_OK) return rc;
+    { char buf[96];
+      if (use_anchor) std::snprintf(buf, sizeof buf, "nb_anchor_kernel<%d>", nr > 5 ? 5 : nr);
+      else std::snprintf(buf, sizeof buf, "nb_lane_kernel<%d, 0>;nb_lane_kernel<%d, 1>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr);
+      c->last_kernels = buf; }
     rc = launch_lane_gather(c, a, ll, c->d_redo_reads, c->d_redo_lens, s); if (rc != NB_OK) return rc;
     BatchArgs b = a;
     b.reads = c->d_redo_reads; b.lens = a.lens ? c->d_redo_lens : nullptr; b.n_dev = c->d_list_counters + 1;

@@ -28,58 +28,6 @@
 
 namespace nb {
 
-// per-lane interning of a one-word set {word index lo, bits a0} in the shared class table; returns the class id or NB_NO_CLASS.
-// Same table protocol as intern_class (nb_kernels.hip): key = content hash, full-content verification through (spans, word).
-__device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, bool want, uint32_t lo, uint64_t a0) {
-  const uint64_t hx = mix64(a0 ^ (0x9E3779B97F4A7C15ull * (uint64_t)(lo + 1u)));
-  const uint64_t key = hx ? hx : 1ull;
-  const uint64_t smask = (1ull << ct.cap_log2) - 1;
-  uint64_t h = (key * HASH_MULT) >> (64 - ct.cap_log2);
-  uint32_t result = NB_NO_CLASS;
-  uint64_t probes = 0;                              // slots passed: the table is full once every slot was seen (intern_class has the same bound)
-  bool pending = want;
-  for (uint32_t it = 0; it < (1u << 24) && __ballot(pending); ++it) {
-    if (pending) {
-      const uint64_t cur = __hip_atomic_load(&ct.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (cur == 0) {
-        unsigned long long expected = 0ull;
-        __hip_atomic_compare_exchange_strong(&ct.keys[h], &expected, (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (expected == 0ull) {                       // this lane owns the slot: allocate, write the row, publish
-          const uint32_t id = __hip_atomic_fetch_add(ct.n_classes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (id >= ct.max_classes) {
-            atomicOr(ct.err, 1u);
-            __hip_atomic_store(&ct.ids[h], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pending = false;
-          } else {
-            for (int w = 0; w < W; ++w)
-              __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)((uint32_t)w == lo ? a0 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ct.spans[id], lo | (lo << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&ct.ids[h], id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            result = id; pending = false;
-          }
-        }
-        // lost the race: look at the same slot again in the next iteration (its key is set now)
-      } else if (cur == key) {
-        const uint32_t idp = __hip_atomic_load(&ct.ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (idp == 0xFFFFFFFFu) pending = false;      // table overflow recorded by the owner
-        else if (idp != 0u) {
-          const uint32_t id = idp - 1u;
-          const uint32_t sp = __hip_atomic_load(&ct.spans[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint64_t word = __hip_atomic_load(&ct.rows[(size_t)id * W + lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (sp == (lo | (lo << 16)) && word == a0) { result = id; pending = false; }
-          else { h = (h + 1) & smask; ++probes; }     // a different set with the same 64-bit hash: keep probing
-        }
-        // idp == 0: the owner is still publishing: poll again in the next iteration
-      } else { h = (h + 1) & smask; ++probes; }
-      if (probes > smask) { atomicOr(ct.err, 1u); pending = false; }
-    }
-  }
-  if (pending) atomicOr(ct.err, 2u);
-  return result;
-}
-
 // highest set bit at a position i <= from with (from - i) % 3 == 0 etc. come from nb_device.h (Mask<NR>, walk_masks_down): they are
 // plain arithmetic on 64-bit words and work per lane as they do per wave.
 
@@ -92,7 +40,6 @@ struct LaneHead {
   const uint32_t* list; const uint32_t* list_n;      // pass 1: reads (bit 31 = map in reverse-complement orientation) and their count
   int pilot_lds_bytes, rec_dwords;                   // dynamic LDS: [pilots][per wave: rec_dwords x 64 dwords]
 };
-struct LaneTail { DevClasses ct; BatchArgs a; LaneLists ll; int W; };
 
 constexpr int LANE_MAX_WAVES = 12;   // = the launch bound of nb_lane_kernel (768 threads: 3 waves per SIMD, up to 168 VGPRs)
 

@@ -90,6 +90,17 @@ class Index:
             return None
         return {"lext": le.value, "rext": re.value, "r_internal": ri.value, "l_internal": li.value, "members": bits_to_members(bits)}
 
+    def anchor_query(self, kmer, run=0):
+        """Anchor structures (csrc/nb_internal.h, AEntry) of a stranded k-mer on the host copy: None or dict(tpos, room, members = the AND
+        of the classes of the text k-mers at [tpos, tpos + min(run, room)])."""
+        tpos, room = ct.c_int64(), ct.c_int32()
+        bits = np.zeros(self.words, dtype=np.uint64)
+        rc = check(_lib.lib().nb_index_anchor_query(self._h, kmer.encode() if isinstance(kmer, str) else kmer, int(run), ct.byref(tpos), ct.byref(room),
+                                                    bits.ctypes.data_as(_lib.c_u64p)))
+        if rc == 0:
+            return None
+        return {"tpos": tpos.value, "room": room.value, "members": bits_to_members(bits)}
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().nb_index_destroy(self._h)

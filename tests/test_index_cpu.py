@@ -86,3 +86,60 @@ def test_index_with_reverse_complement_sequences(built):
     probes += [p.translate(comp)[::-1] for p in probes[::2]] + ["".join("ACGT"[c] for c in rng.integers(0, 4, 20)) for _ in range(3000)]
     for p in probes:
         assert ix.query(p) == ox.query(p), p
+
+
+@pytest.mark.parametrize("with_rc", [False, True])
+def test_anchor_structures(built, with_rc):
+    """Anchor structures of the anchor-extend kernel (csrc/nb_internal.h, AEntry): for library k-mers and their neighbours
+      * the anchor is an occurrence (the first one) of the k-mer in the concatenated library text,
+      * room = how far the text can be followed from there: next k-mers valid (no N, same sequence), not present on both strands, < 255,
+      * the sparse-table AND over [tpos, tpos + run] equals the AND of the classes nb_index_query reports for those text k-mers,
+    and k-mers that are absent, or present on both strands, have no anchor."""
+    _, _, strs, _ = library_strings(3, 6, locus_len=420, seed=17)
+    strs[2] = strs[2][:100] + "N" + strs[2][101:]
+    comp = str.maketrans("ACGTN", "TGCAN")
+    if with_rc:
+        strs = strs + [strs[4].translate(comp)[::-1], strs[7][:200]]
+    K = 20
+    ix = engine.Index(strs, K)
+    assert ix.stats()["anchor_bytes"] > 0
+    text = "".join(s.upper() for s in strs)
+    starts = np.cumsum([0] + [len(s) for s in strs])
+    seq_of = np.repeat(np.arange(len(strs)), [len(s) for s in strs])
+
+    def kmer_at(t):
+        return text[t:t + K] if t + K <= len(text) and seq_of[t] == seq_of[t + K - 1] and "N" not in text[t:t + K] else None
+
+    first, info = {}, {}
+    for t in range(len(text)):
+        km = kmer_at(t)
+        if km is not None:
+            first.setdefault(km, t)
+            if km not in info:
+                info[km] = (ix.query(km), ix.query(km.translate(comp)[::-1]) is not None)
+    checked = both = 0
+    for km, t0 in list(first.items())[::3]:
+        q, is_both = info[km]
+        a = ix.anchor_query(km, 0)
+        if is_both:
+            assert a is None
+            both += 1
+            continue
+        assert a is not None and a["tpos"] == t0 and a["members"] == q["members"]
+        room = 0
+        while room < 254:
+            nxt = kmer_at(t0 + room + 1)
+            if nxt is None or info[nxt][1]:
+                break
+            room += 1
+        assert a["room"] == room, (km, t0)
+        for run in {0, 1, 2, 3, 7, 8, 31, 64, 100, 254, room}:
+            want = set(q["members"])
+            for i in range(1, min(run, room) + 1):
+                want &= set(info[kmer_at(t0 + i)][0]["members"])
+            assert ix.anchor_query(km, run)["members"] == sorted(want), (km, run)
+        checked += 1
+    assert checked > 800 and (both > 100) == with_rc
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        assert ix.anchor_query("".join("ACGT"[c] for c in rng.integers(0, 4, K))) is None
