@@ -35,6 +35,61 @@ struct AnchorHead {
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
 
+
+// ---- per-lane record in LDS (column `lane` of rec[]: dword j at rec[j * 64 + lane]) ------------------------------------------------------
+// layout: [0, nbd) packed bases, [nbd, nbd + nd) N bits, two zero dwords. stream_rc() rewrites the column IN PLACE as the reverse complement
+// of the read, so that every later access is a plain forward window whatever the orientation.
+struct Rec {
+  uint32_t* col; int nbd, nd, L;
+  __device__ __forceinline__ uint32_t& at(int j) const { return col[j * 64]; }
+  // 32 stream bases from position q (2 bits each, first base at bit 0) and their N-or-beyond-the-read bits
+  __device__ __forceinline__ void get32(int q, uint64_t& win, uint32_t& nwin) const {
+    const int j = q >> 4; const uint32_t sh = 2u * ((uint32_t)q & 15u);
+    const uint32_t d0 = at(j), d1 = at(j + 1), d2 = at(j + 2);
+    const uint64_t lo = ((uint64_t)d1 << 32) | d0;
+    win = sh ? ((lo >> sh) | ((uint64_t)d2 << (64u - sh))) : lo;
+    const int jn = nbd + (q >> 5); const uint32_t shn = (uint32_t)q & 31u;
+    const uint64_t nn = ((uint64_t)at(jn + 1) << 32) | at(jn);
+    uint32_t n = (uint32_t)(nn >> shn);
+    const int left = L - q;
+    n |= left >= 32 ? 0u : (left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << left));
+    nwin = n;
+  }
+  __device__ __forceinline__ void stream_rc() const {
+    // bases: reverse the dword order, reverse the bases inside each dword, complement; then shift the read's end down to position 0
+    for (int j = 0; j < nbd / 2; ++j) {
+      uint32_t a = at(j), b = at(nbd - 1 - j);
+      a = __brev(a); a = ~(((a & 0x55555555u) << 1) | ((a >> 1) & 0x55555555u));
+      b = __brev(b); b = ~(((b & 0x55555555u) << 1) | ((b >> 1) & 0x55555555u));
+      at(j) = b; at(nbd - 1 - j) = a;
+    }
+    { const int s = 2 * (16 * nbd - L), qd = s >> 5; const uint32_t r = (uint32_t)s & 31u;
+      for (int j = 0; j < nbd; ++j) {
+        const uint32_t x0 = j + qd < nbd ? at(j + qd) : 0u, x1 = j + qd + 1 < nbd ? at(j + qd + 1) : 0u;
+        at(j) = r ? ((x0 >> r) | (x1 << (32u - r))) : x0;
+      } }
+    for (int j = 0; j < nd / 2; ++j) {
+      const uint32_t a = __brev(at(nbd + j)), b = __brev(at(nbd + nd - 1 - j));
+      at(nbd + j) = b; at(nbd + nd - 1 - j) = a;
+    }
+    { const int s = 32 * nd - L, qd = s >> 5; const uint32_t r = (uint32_t)s & 31u;
+      for (int j = 0; j < nd; ++j) {
+        const uint32_t x0 = j + qd < nd ? at(nbd + j + qd) : 0u, x1 = j + qd + 1 < nd ? at(nbd + j + qd + 1) : 0u;
+        at(nbd + j) = r ? ((x0 >> r) | (x1 << (32u - r))) : x0;
+      } }
+  }
+};
+
+struct Look { uint4 e; uint32_t want; bool o; };
+__device__ __forceinline__ Look anchor_lookup(const AnchorHead& h, const uint8_t* s_pilots, uint64_t x, bool valid) {
+  const uint64_t y = rc_kmer(x, h.K);
+  Look k; k.o = x > y;
+  const PHProbe pr = ph_probe(k.o ? y : x, h.ph);
+  k.want = pr.want;
+  k.e = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_slot(pr, (uint32_t)s_pilots[pr.group], h.ph) : 0u]);
+  return k;
+}
+
 template <int NR>
 __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -43,7 +98,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wpb = (int)(blockDim.x >> 6);
-  uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;   // dword j of this lane's record at rec[j * 64 + lane]
+  uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
     *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
@@ -53,7 +108,8 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
   const uint64_t kmask = (1ull << (2 * K)) - 1;
   const uint32_t nkmask = (1u << K) - 1u;
   const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1;
-  constexpr uint32_t F_SEEDED = 1u, F_STARTED = 2u, F_SLOW = 4u, F_HARD = 8u, F_OPP = 16u, F_LEXT = 32u, F_ERR = 64u;
+  constexpr uint32_t F_SEEDED = 1u, F_STARTED = 2u, F_SLOW = 4u, F_HARD = 8u, F_OPP = 16u, F_LEXT = 32u, F_ERR = 64u, F_STEP = 128u;
+  constexpr uint32_t F_REDO = F_SLOW | F_HARD | F_OPP | F_LEXT | F_ERR;
 
   for (long long base = ((long long)blockIdx.x * wpb + wave) * 64; base < h.n; base += nwaves * 64) {
     const long long idx = base + lane;
@@ -61,103 +117,88 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     const uint32_t r = active ? (uint32_t)idx : 0u;
     int L = 0;
     if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
+    Rec R{rec + lane, 2 * nwb, 2 * nwn, L};
     {   // stage the record (this lane's column of LDS)
       const uint64_t* __restrict__ rp = h.reads + (size_t)r * h.stride;
       for (int j = 0; j < nwb + nwn; ++j) {
         const uint64_t w = active ? rp[j] : 0ull;
-        rec[(2 * j) * 64 + lane] = (uint32_t)w; rec[(2 * j + 1) * 64 + lane] = (uint32_t)(w >> 32);
+        R.at(2 * j) = (uint32_t)w; R.at(2 * j + 1) = (uint32_t)(w >> 32);
       }
-      rec[(2 * (nwb + nwn)) * 64 + lane] = 0u; rec[(2 * (nwb + nwn) + 1) * 64 + lane] = 0u;
+      R.at(2 * (nwb + nwn)) = 0u; R.at(2 * (nwb + nwn) + 1) = 0u;
     }
     const int last = L - K;
     bool rcf = false;                            // stream = reverse complement of the read
     uint32_t fl = 0;
+    bool to_scan = false;
 
-    // 16 bases of the stream from stream position q (2 bits each, first base at bit 0) and their N-or-beyond-the-read bits
-    auto get16 = [&](int q, uint32_t& win, uint32_t& nwin) {
-      int hi = L - 1 - q; hi = hi < 0 ? 0 : hi;                        // reverse lanes: the 16 bases ENDING at read base hi, reversed and complemented
-      const int jf = q >> 4, jr = hi >> 4, jr1 = jr > 0 ? jr - 1 : 0;
-      const uint32_t A = rec[(rcf ? jr : jf + 1) * 64 + lane], B = rec[(rcf ? jr1 : jf) * 64 + lane];
-      uint32_t w = (uint32_t)((((uint64_t)A << 32) | B) >> (rcf ? 2 * ((hi & 15) + 1) : 2 * (q & 15)));
-      uint32_t rev = __brev(w); rev = ((rev & 0x55555555u) << 1) | ((rev >> 1) & 0x55555555u);
-      win = rcf ? ~rev : w;
-      const int nb0 = 2 * nwb, nf = q >> 5, nr_ = hi >> 5, nr1 = nr_ > 0 ? nr_ - 1 : 0;
-      const uint32_t NA = rec[(nb0 + (rcf ? nr_ : nf + 1)) * 64 + lane], NB = rec[(nb0 + (rcf ? nr1 : nf)) * 64 + lane];
-      uint32_t nw = (uint32_t)((((uint64_t)NA << 32) | NB) >> (rcf ? (hi & 31) + 17 : (q & 31))) & 0xFFFFu;
-      nw = rcf ? (__brev(nw) >> 16) : nw;
-      const int left = L - q;                                          // stream positions of this window that lie inside the read
-      nw |= left >= 16 ? 0u : (left <= 0 ? 0xFFFFu : ((0xFFFFu << left) & 0xFFFFu));
-      nwin = nw;
-    };
-    // 32 bases from stream position q
-    auto get32 = [&](int q, uint64_t& win, uint32_t& nwin) {
-      uint32_t w0, n0, w1, n1; get16(q, w0, n0); get16(q + 16, w1, n1);
-      win = ((uint64_t)w1 << 32) | w0; nwin = (n1 << 16) | n0;
-    };
-    // one table lookup: canonical k-mer -> slot (pilot from LDS) -> entry
-    struct Look { uint4 e; uint32_t want; bool o; };
-    auto lookup = [&](uint64_t x, bool valid) {
-      const uint64_t y = rc_kmer(x, K);
-      Look k; k.o = x > y;
-      const PHProbe pr = ph_probe(k.o ? y : x, h.ph);
-      k.want = pr.want;
-      k.e = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_slot(pr, (uint32_t)s_pilots[pr.group], h.ph) : 0u]);
-      return k;
-    };
-
-    // ---- orientation: which strand do the k-mers at the start, the middle and the end of the read hit? ----
+    // ---- orientation: which strand do the k-mers at the start, the middle and the end of the read hit? A read none of whose three
+    // probes is in the table at all is most likely foreign to the library: the scan kernel settles it (no walk, no divergence here) ----
     if (last >= 0) {
-      int votes = 0;
+      int votes = 0; bool any = false;
       Look pk[3]; bool pv[3];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int p = u == 0 ? 0 : (u == 1 ? last >> 1 : last);
-        uint64_t w; uint32_t nn; get32(p, w, nn);
+        uint64_t w; uint32_t nn; R.get32(p, w, nn);
         pv[u] = (nn & nkmask) == 0;
-        pk[u] = lookup(w & kmask, pv[u]);
+        pk[u] = anchor_lookup(h, s_pilots, w & kmask, pv[u]);
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const uint32_t d = pk[u].e.x ^ pk[u].want;
-        if (pv[u] && d < 4u && !(d & 2u)) votes += ((d & 1u) == (pk[u].o ? 1u : 0u)) ? 1 : -1;
+        if (pv[u] && d < 4u) { any = true; if (!(d & 2u)) votes += ((d & 1u) == (pk[u].o ? 1u : 0u)) ? 1 : -1; }
       }
       rcf = votes < 0;
+      to_scan = active && !any;
+      if (rcf) R.stream_rc();
     }
 
-    // ---- the walk, in rounds: one lookup per lane and round, followed by the run along the text if it succeeds ----
-    int mode = (active && last >= 0) ? 0 : 2;   // 0 = SEEK a seed at `pos` (stride 3), 1 = STEP over stream base `pos`, 2 = done
+    // ---- the walk, in rounds. A lane is seeking a seed (SEEK, stride 3), stepping over the base its last run stopped at (STEP), following
+    // the text (EXT: one 32-base comparison per round) or done. One lookup and one comparison per round at the most. ----
+    constexpr int SEEK = 0, STEP = 1, EXT = 2, DONE = 3;
+    int mode = (active && last >= 0 && !to_scan) ? SEEK : DONE;
     int pos = 0, cov = 0;
     uint32_t lo = 0; uint64_t a0 = 0;
+    uint32_t run_t = 0, run_pay = 0; int run_q = 0, steps = 0, maxsteps = 0;   // the run being followed: text position / payload of its first k-mer, ...
     Mask<NR> cover;                             // positions whose status on BOTH strands is known: looked up, or inside a verified run
 #pragma unroll
     for (int wi = 0; wi < NR; ++wi) cover.w[wi] = 0;
     const int L5 = L / 5;
     int rounds = 0;
-    while (__ballot(mode != 2)) {
-      const bool act = mode != 2;
-      const bool step = mode == 1;
-      const int q = act ? (step ? pos - K + 1 : pos) : 0;             // k-mer position of this round's lookup
-      uint64_t w; uint32_t nn; get32(q - (step ? 1 : 0), w, nn);      // (STEP: one base earlier, for the left-extension test; q >= 1 there)
-      const uint32_t pb = (uint32_t)w & 3u;
-      const uint64_t x = (step ? (w >> 2) : w) & kmask;
-      const bool valid = act && (((step ? (nn >> 1) : nn) & nkmask) == 0);
-      const Look k = lookup(x, valid);
-      const uint32_t d = k.e.x ^ k.want, pay = k.e.y;
-      const bool found = valid && d < 4u, both = found && (d & 2u);
-      const bool hS = found && !both && ((d & 1u) == (k.o ? 1u : 0u));
-      fl |= (both ? F_HARD : 0u) | ((found && !both && !hS) ? F_OPP : 0u);
-      const bool ok = hS && (!step || ((pay >> (4u + pb)) & 1u));
-      // the run: compare the stream from base q + K with the text from tpos + K, 32 bases per step, at most `room` steps
-      const uint32_t tpos = k.e.z;
-      int steps = 0;
-      const int b0 = q + K;
-      int maxsteps = 0;
-      if (ok) { maxsteps = (int)(k.e.w & 0xFFFFu); const int rem = L - b0; maxsteps = maxsteps < rem ? maxsteps : rem; }
-      bool ext = maxsteps > 0;
-      while (__ballot(ext)) {
-        if (ext) {
-          uint64_t sw; uint32_t sn; get32(b0 + steps, sw, sn);
-          const uint32_t tb = tpos + (uint32_t)(K + steps);
+    while (__ballot(mode != DONE)) {
+      if (__ballot(mode == SEEK || mode == STEP)) {
+        const bool act = mode == SEEK || mode == STEP;
+        const bool step = mode == STEP;
+        const int q = act ? (step ? pos - K + 1 : pos) : 0;           // k-mer position of this round's lookup
+        uint64_t w; uint32_t nn; R.get32(q - (step ? 1 : 0), w, nn);  // (STEP: one base earlier, for the left-extension test; q >= 1 there)
+        const uint32_t pb = (uint32_t)w & 3u;
+        const uint64_t x = (step ? (w >> 2) : w) & kmask;
+        const bool valid = act && (((step ? (nn >> 1) : nn) & nkmask) == 0);
+        const Look k = anchor_lookup(h, s_pilots, x, valid);
+        const uint32_t d = k.e.x ^ k.want, pay = k.e.y;
+        const bool found = valid && d < 4u, both = found && (d & 2u);
+        const bool hS = found && !both && ((d & 1u) == (k.o ? 1u : 0u));
+        fl |= (both ? F_HARD : 0u) | ((found && !both && !hS) ? F_OPP : 0u);
+        const bool ok = hS && (!step || ((pay >> (4u + pb)) & 1u));
+        if (ok) {
+          if (!step && !(fl & F_SEEDED) && q >= L5 && q > 0) fl |= F_LEXT;    // the first seed may have a left extension: wave-per-read kernel
+          fl = (fl & ~F_STEP) | (step ? F_STEP : 0u) | F_SEEDED;
+          run_t = k.e.z; run_pay = pay; run_q = q; steps = 0;
+          const int room = (int)(k.e.w & 0xFFFFu), rem = L - (q + K);
+          maxsteps = room < rem ? room : rem;
+          mode = EXT;
+        } else if (act) {
+          set_range<NR>(cover, q, q);
+          if (step) mode = pos > last ? DONE : SEEK;                          // the walk broke at base pos: seed scan from there (SPEC §3)
+          else { pos += 3; mode = pos > last ? DONE : SEEK; }
+        }
+      }
+      if (__ballot(mode == EXT)) {
+        const bool ex = mode == EXT;
+        bool fin = ex;
+        if (ex && steps < maxsteps) {
+          uint64_t sw; uint32_t sn; R.get32(run_q + K + steps, sw, sn);
+          const uint32_t tb = run_t + (uint32_t)(K + steps);
           const U3 tw3 = *reinterpret_cast<const U3*>(h.text + (tb >> 4));
           const uint32_t sh = 2u * (tb & 15u);
           const uint64_t t01 = ((uint64_t)tw3.b << 32) | tw3.a;
@@ -168,39 +209,33 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
           const int fn = sn ? __builtin_ctz(sn) : 32;
           const int m = fm < fn ? fm : fn;
           const int room_left = maxsteps - steps;
-          const int take = m < room_left ? m : room_left;
-          steps += take;
-          ext = (m == 32) && steps < maxsteps;
+          steps += m < room_left ? m : room_left;
+          fin = (m < 32) || steps >= maxsteps;
+        }
+        if (fin) {                                                            // the run [run_q, run_q + steps] is complete
+          cov += ((fl & F_STEP) ? 1 : K) + steps;
+          const uint32_t n = (uint32_t)steps + 1u;
+          const int lv = 31 - __builtin_clz(n);
+          const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + run_t;
+          const uint64_t v = sp[0] & sp[n - (1u << lv)];
+          const uint32_t w0 = run_pay >> 11;
+          const bool first = !(fl & F_STARTED);
+          a0 = first ? v : ((w0 == lo) ? (a0 & v) : 0ull);
+          lo = first ? w0 : lo;
+          fl |= F_STARTED | ((run_pay & (1u << 10)) ? F_SLOW : 0u);
+          set_range<NR>(cover, run_q, run_q + steps);
+          pos = run_q + K + steps;                                            // the base the run stopped at
+          mode = pos >= L ? DONE : STEP;
         }
       }
-      if (ok) {
-        if (!step && !(fl & F_SEEDED) && q >= L5 && q > 0) fl |= F_LEXT;      // the first seed may have a left extension: wave-per-read kernel
-        cov += (step ? 1 : K) + steps;
-        const uint32_t n = (uint32_t)steps + 1u;
-        const int lv = 31 - __builtin_clz(n);
-        const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + tpos;
-        const uint64_t v = sp[0] & sp[n - (1u << lv)];
-        const uint32_t w0 = pay >> 11;
-        const bool first = !(fl & F_STARTED);
-        a0 = first ? v : ((w0 == lo) ? (a0 & v) : 0ull);
-        lo = first ? w0 : lo;
-        fl |= F_SEEDED | F_STARTED | ((pay & (1u << 10)) ? F_SLOW : 0u);
-        set_range<NR>(cover, q, q + steps);
-        pos = b0 + steps;                                                     // the base the run stopped at
-        mode = pos >= L ? 2 : 1;
-      } else if (act) {
-        if (valid) set_range<NR>(cover, q, q);
-        if (step) mode = pos > last ? 2 : 0;                                  // the walk broke at base pos: seed scan from there (SPEC §3)
-        else { pos += 3; mode = pos > last ? 2 : 0; }
-      }
-      if (++rounds > 4 * h.max_len + 8) { fl |= act ? F_ERR : 0u; mode = 2; }  // (cannot happen: every two rounds advance pos; an exit every wave reaches)
+      if (++rounds > 6 * h.max_len + 16) { fl |= (mode != DONE) ? F_ERR : 0u; mode = DONE; }   // (cannot happen: every round advances a lane; an exit every wave reaches)
     }
 
     // ---- the other orientation: does any of ITS seed-scan positions hit? (stream positions p = last, last - 3, ... not yet known) ----
     {
       Mask<NR> todo;
       const uint64_t PAT = 0x9249249249249249ull;
-      const bool need = active && last >= 0 && !(fl & (F_HARD | F_OPP | F_LEXT | F_SLOW | F_ERR));
+      const bool need = active && last >= 0 && !to_scan && !(fl & F_REDO);
 #pragma unroll
       for (int wi = 0; wi < NR; ++wi) {
         const int res = ((last % 3) - (wi % 3) + 3) % 3;
@@ -216,16 +251,16 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
           int p = -1;
 #pragma unroll
           for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
-          uint64_t w; uint32_t nn; get32(p < 0 ? 0 : p, w, nn);
+          uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
           vv[u] = p >= 0 && (nn & nkmask) == 0;
-          kk[u] = lookup(w & kmask, vv[u]);
+          kk[u] = anchor_lookup(h, s_pilots, w & kmask, vv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const uint32_t d = kk[u].e.x ^ kk[u].want;
           const bool found = vv[u] && d < 4u;
           const bool mine = found && !(d & 2u) && ((d & 1u) == (kk[u].o ? 1u : 0u));
-          if (found && !mine) { fl |= F_OPP; }
+          if (found && !mine) fl |= F_OPP;
         }
         if (fl & F_OPP) {
 #pragma unroll
@@ -234,7 +269,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       }
     }
 
-    // ---- SPEC §4 per lane, outputs, redo list ----
+    // ---- SPEC §4 per lane, outputs, lists ----
     asm volatile("" ::: "memory");
     const LaneTail& T = *tp;
     const BatchArgs& a = T.a;
@@ -242,8 +277,8 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0;
     uint32_t cls = NB_NO_CLASS;
     bool to_redo = false, final_ = false, call = false;
-    if (active && L >= K) {
-      if (fl & (F_HARD | F_OPP | F_LEXT | F_SLOW | F_ERR)) to_redo = true;
+    if (active && L >= K && !to_scan) {
+      if (fl & F_REDO) to_redo = true;
       else {
         final_ = true;                                                        // the other orientation has no hit: its coverage is 0 (NO_HIT)
         if (a.out_cov) a.out_cov[r] = rcf ? ((uint64_t)(cov & 0xFFFF) << 16) : (uint64_t)(cov & 0xFFFF);
@@ -257,7 +292,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         if (rs) reason = rs;
         else { score = cov; orient = rcf ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
       }
-    } else if (active) { final_ = true; if (a.out_cov) a.out_cov[r] = 0ull; }
+    } else if (active && !to_scan) { final_ = true; if (a.out_cov) a.out_cov[r] = 0ull; }
     cls = intern_lane(T.ct, T.W, call, lo, a0);
     if (call && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], 1ull);
     if (active && final_) {
@@ -265,8 +300,14 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
       if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
     }
-    {
-      const uint64_t mredo = __ballot(to_redo);
+    {   // worklists: wave ballot + prefix count, one atomic per wave and list
+      const uint64_t ms = __ballot(to_scan), mredo = __ballot(to_redo);
+      if (ms) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&T.ll.counters[0], (uint32_t)__popcll(ms));
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        if (to_scan) T.ll.rc_list[b0 + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = r;
+      }
       if (mredo) {
         uint32_t b0 = 0;
         if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
@@ -279,6 +320,93 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
 
+// The reads none of whose three probes was in the table (ll.rc_list): every seed-scan position of BOTH orientations is looked up, all lanes
+// in lock-step, four lookups in flight per lane. No k-mer found at all: NO_HIT in both orientations, final. Anything found: redo list.
+template <int NR>
+__global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  __shared__ unsigned int s_nohit;
+  uint8_t* s_pilots = s_dyn;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wpb = (int)(blockDim.x >> 6);
+  uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
+  const LaneTail& T = *tp;
+  const long long count = (long long)T.ll.counters[0];
+  if (threadIdx.x == 0) s_nohit = 0;
+  if (count > 0)
+    for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
+      *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
+  __syncthreads();
+  const long long nwaves = (long long)gridDim.x * wpb;
+  const int K = h.K;
+  const uint64_t kmask = (1ull << (2 * K)) - 1;
+  const uint32_t nkmask = (1u << K) - 1u;
+  const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1;
+  for (long long base = ((long long)blockIdx.x * wpb + wave) * 64; base < count; base += nwaves * 64) {
+    const long long idx = base + lane;
+    const bool active = idx < count;
+    const uint32_t r = active ? T.ll.rc_list[idx] : 0u;
+    int L = 0;
+    if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
+    Rec R{rec + lane, 2 * nwb, 2 * nwn, L};
+    {
+      const uint64_t* __restrict__ rp = h.reads + (size_t)r * h.stride;
+      for (int j = 0; j < nwb + nwn; ++j) {
+        const uint64_t w = active ? rp[j] : 0ull;
+        R.at(2 * j) = (uint32_t)w; R.at(2 * j + 1) = (uint32_t)(w >> 32);
+      }
+      R.at(2 * (nwb + nwn)) = 0u; R.at(2 * (nwb + nwn) + 1) = 0u;
+    }
+    const int last = L - K;
+    Mask<NR> todo;
+    const uint64_t PAT = 0x9249249249249249ull;
+#pragma unroll
+    for (int wi = 0; wi < NR; ++wi) {                                       // p % 3 == 0 (forward seed scan) or p % 3 == last % 3 (the other orientation's)
+      const int r0 = (3 - (wi % 3)) % 3, r1 = ((last % 3) - (wi % 3) + 3) % 3;
+      uint64_t m = (PAT << r0) | (PAT << r1);
+      const int top = last - wi * 64;
+      m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
+      todo.w[wi] = (active && last >= 0) ? m : 0ull;
+    }
+    bool hit = false;
+    while (__ballot(any_set<NR>(todo))) {
+      Look kk[4]; bool vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int p = -1;
+#pragma unroll
+        for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
+        uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
+        vv[u] = p >= 0 && (nn & nkmask) == 0;
+        kk[u] = anchor_lookup(h, s_pilots, w & kmask, vv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hit = hit || (vv[u] && ((kk[u].e.x ^ kk[u].want) < 4u));
+      if (hit) {
+#pragma unroll
+        for (int wi = 0; wi < NR; ++wi) todo.w[wi] = 0;
+      }
+    }
+    const BatchArgs& a = T.a;
+    if (active && !hit) {
+      atomicAdd(&s_nohit, 1u);
+      if (a.out_class) a.out_class[r] = NB_NO_CLASS;
+      if (a.out_info) a.out_info[r] = (uint32_t)NB_NO_HIT << 16;
+      if (a.out_cov) a.out_cov[r] = 0ull;
+    }
+    const uint64_t mredo = __ballot(active && hit);
+    if (mredo) {
+      uint32_t b0 = 0;
+      if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
+      b0 = __builtin_amdgcn_readfirstlane(b0);
+      if (active && hit) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_nohit) atomicAdd(&tp->ct.reasons[NB_NO_HIT], (unsigned long long)s_nohit);
+}
+
 template <int NR>
 static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
   NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -286,6 +414,9 @@ static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tai
   const long long need = (h.n + 64LL * waves - 1) / (64LL * waves);
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL((nb_anchor_kernel<NR>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
+  NB_HIP(hipGetLastError());
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (list length: on the device)
   NB_HIP(hipGetLastError());
   return NB_OK;
 }

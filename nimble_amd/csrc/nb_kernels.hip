@@ -1360,7 +1360,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     const bool use_anchor = c->has_anchor && !(anchor_env && anchor_env[0] == '0');
     rc = use_anchor ? launch_anchor(c, nr, ix, a, ll, s) : launch_lane(c, nr, ix, a, ll, s); if (rc != NB_OK) return rc;
     { char buf[96];
-      if (use_anchor) std::snprintf(buf, sizeof buf, "nb_anchor_kernel<%d>", nr > 5 ? 5 : nr);
+      if (use_anchor) std::snprintf(buf, sizeof buf, "nb_anchor_kernel<%d>;nb_anchor_scan_kernel<%d>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr);
       else std::snprintf(buf, sizeof buf, "nb_lane_kernel<%d, 0>;nb_lane_kernel<%d, 1>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr);
       c->last_kernels = buf; }
     rc = launch_lane_gather(c, a, ll, c->d_redo_reads, c->d_redo_lens, s); if (rc != NB_OK) return rc;
