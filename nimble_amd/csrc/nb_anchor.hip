@@ -35,6 +35,15 @@ struct AnchorHead {
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
 
+#ifdef NB_ANCHOR_PROF   // phase clock for tuning (-DNB_ANCHOR_PROF through NB_EXTRA_HIPCC_FLAGS): cycles per phase summed over waves, see scripts/anchor_phases.py
+__device__ unsigned long long g_anchor_prof[16];
+#define PROF_MARK(slot) do { const long long t_ = clock64(); pacc[slot] += (unsigned long long)(t_ - tprof); tprof = t_; } while (0)
+#define PROF_COUNT(slot, v) do { pacc[slot] += (unsigned long long)(v); } while (0)
+#else
+#define PROF_MARK(slot) do {} while (0)
+#define PROF_COUNT(slot, v) do {} while (0)
+#endif
+
 
 // ---- per-lane record in LDS (column `lane` of rec[]: dword j at rec[j * 64 + lane]) ------------------------------------------------------
 // layout: [0, nbd) packed bases, [nbd, nbd + nd) N bits, two zero dwords. stream_rc() rewrites the column IN PLACE as the reverse complement
@@ -91,7 +100,7 @@ __device__ __forceinline__ Look anchor_lookup(const AnchorHead& h, const uint8_t
 }
 
 template <int NR>
-__global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
+__global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   uint8_t* s_pilots = s_dyn;
@@ -110,6 +119,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
   const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1;
   constexpr uint32_t F_SEEDED = 1u, F_STARTED = 2u, F_SLOW = 4u, F_HARD = 8u, F_OPP = 16u, F_LEXT = 32u, F_ERR = 64u, F_STEP = 128u;
   constexpr uint32_t F_REDO = F_SLOW | F_HARD | F_OPP | F_LEXT | F_ERR;
+#ifdef NB_ANCHOR_PROF
+  unsigned long long pacc[16] = {0};
+#endif
 
   for (long long base = ((long long)blockIdx.x * wpb + wave) * 64; base < h.n; base += nwaves * 64) {
     const long long idx = base + lane;
@@ -118,6 +130,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     int L = 0;
     if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
     Rec R{rec + lane, 2 * nwb, 2 * nwn, L};
+#ifdef NB_ANCHOR_PROF
+    long long tprof = clock64();
+#endif
     {   // stage the record (this lane's column of LDS)
       const uint64_t* __restrict__ rp = h.reads + (size_t)r * h.stride;
       for (int j = 0; j < nwb + nwn; ++j) {
@@ -130,6 +145,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     bool rcf = false;                            // stream = reverse complement of the read
     uint32_t fl = 0;
     bool to_scan = false;
+    PROF_MARK(0);
 
     // ---- orientation: which strand do the k-mers at the start, the middle and the end of the read hit? A read none of whose three
     // probes is in the table at all is most likely foreign to the library: the scan kernel settles it (no walk, no divergence here) ----
@@ -153,6 +169,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       if (rcf) R.stream_rc();
     }
 
+    PROF_MARK(1);
     // ---- the walk, in rounds. A lane is seeking a seed (SEEK, stride 3), stepping over the base its last run stopped at (STEP), following
     // the text (EXT: one 32-base comparison per round) or done. One lookup and one comparison per round at the most. ----
     constexpr int SEEK = 0, STEP = 1, EXT = 2, DONE = 3;
@@ -160,6 +177,17 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     int pos = 0, cov = 0;
     uint32_t lo = 0; uint64_t a0 = 0;
     uint32_t run_t = 0, run_pay = 0; int run_q = 0, steps = 0, maxsteps = 0;   // the run being followed: text position / payload of its first k-mer, ...
+    uint64_t pv0 = ~0ull, pv1 = ~0ull; uint32_t pw0 = 0; bool pend = false;     // class words of the last finished run: loaded, not yet waited for
+    auto apply_pending = [&]() {                 // (the AND is folded in one run later, so that the two sparse-table loads never stall a round)
+      if (pend) {
+        const uint64_t v = pv0 & pv1;
+        const bool first = !(fl & F_STARTED);
+        a0 = first ? v : ((pw0 == lo) ? (a0 & v) : 0ull);
+        lo = first ? pw0 : lo;
+        fl |= F_STARTED;
+        pend = false;
+      }
+    };
     Mask<NR> cover;                             // positions whose status on BOTH strands is known: looked up, or inside a verified run
 #pragma unroll
     for (int wi = 0; wi < NR; ++wi) cover.w[wi] = 0;
@@ -217,12 +245,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
           const uint32_t n = (uint32_t)steps + 1u;
           const int lv = 31 - __builtin_clz(n);
           const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + run_t;
-          const uint64_t v = sp[0] & sp[n - (1u << lv)];
-          const uint32_t w0 = run_pay >> 11;
-          const bool first = !(fl & F_STARTED);
-          a0 = first ? v : ((w0 == lo) ? (a0 & v) : 0ull);
-          lo = first ? w0 : lo;
-          fl |= F_STARTED | ((run_pay & (1u << 10)) ? F_SLOW : 0u);
+          apply_pending();
+          pv0 = sp[0]; pv1 = sp[n - (1u << lv)]; pw0 = run_pay >> 11; pend = true;
+          fl |= (run_pay & (1u << 10)) ? F_SLOW : 0u;
           set_range<NR>(cover, run_q, run_q + steps);
           pos = run_q + K + steps;                                            // the base the run stopped at
           mode = pos >= L ? DONE : STEP;
@@ -230,6 +255,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       }
       if (++rounds > 6 * h.max_len + 16) { fl |= (mode != DONE) ? F_ERR : 0u; mode = DONE; }   // (cannot happen: every round advances a lane; an exit every wave reaches)
     }
+
+    apply_pending();
+    PROF_MARK(2); PROF_COUNT(8, rounds); PROF_COUNT(9, 1);
 
     // ---- the other orientation: does any of ITS seed-scan positions hit? (stream positions p = last, last - 3, ... not yet known) ----
     {
@@ -269,6 +297,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       }
     }
 
+    PROF_MARK(3);
     // ---- SPEC §4 per lane, outputs, lists ----
     asm volatile("" ::: "memory");
     const LaneTail& T = *tp;
@@ -293,7 +322,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         else { score = cov; orient = rcf ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
       }
     } else if (active && !to_scan) { final_ = true; if (a.out_cov) a.out_cov[r] = 0ull; }
+    PROF_MARK(4);
     cls = intern_lane(T.ct, T.W, call, lo, a0);
+    PROF_MARK(5);
     if (call && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], 1ull);
     if (active && final_) {
       atomicAdd(&s_reason[reason], 1u);
@@ -315,7 +346,11 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         if (to_redo) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
       }
     }
+    PROF_MARK(6);
   }
+#ifdef NB_ANCHOR_PROF
+  if (lane == 0) for (int i = 0; i < 16; ++i) if (pacc[i]) atomicAdd(&g_anchor_prof[i], pacc[i]);
+#endif
   __syncthreads();
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
@@ -323,7 +358,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
 // The reads none of whose three probes was in the table (ll.rc_list): every seed-scan position of BOTH orientations is looked up, all lanes
 // in lock-step, four lookups in flight per lane. No k-mer found at all: NO_HIT in both orientations, final. Anything found: redo list.
 template <int NR>
-__global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
+__global__ __launch_bounds__(1024) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_nohit;
   uint8_t* s_pilots = s_dyn;
@@ -407,6 +442,20 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
   if (threadIdx.x == 0 && s_nohit) atomicAdd(&tp->ct.reasons[NB_NO_HIT], (unsigned long long)s_nohit);
 }
 
+// dynamic LDS of one workgroup: first level of the table + record staging of up to 16 waves (the kernels need ~65 VGPRs: the LDS is
+// what limits the waves per CU, and the walk is a chain of dependent loads, i.e. it runs at waves in flight / latency)
+static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block) {
+  const int nwb = (max_len + 31) / 32, nwn = (max_len + 63) / 64;
+  const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4, pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
+  const int64_t budget = (160 << 10) - 256;
+  int w = 16;
+  if (const char* e = std::getenv("NB_ANCHOR_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) w = v; }
+  while (w > 0 && pil + (int64_t)w * rec > budget) --w;
+  if (w < 8) return 0;
+  if (waves_per_block) *waves_per_block = w;
+  return pil + (int64_t)w * rec;
+}
+
 template <int NR>
 static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
   NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -423,7 +472,7 @@ static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tai
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
   int waves = 0;
-  const int64_t lds = lane_lds_bytes(c, a.max_len, &waves);
+  const int64_t lds = anchor_lds_bytes(c, a.max_len, &waves);
   if (lds <= 0 || !c->has_anchor) { set_error("launch_anchor: shape does not fit"); return NB_ERR_UNSUPPORTED; }
   NB_HIP(hipMemsetAsync(ll.counters, 0, 8, s));
   if (!c->d_lane_tail) NB_HIP(hipMalloc((void**)&c->d_lane_tail, sizeof(LaneTail)));
@@ -443,3 +492,11 @@ int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, con
 }
 
 }  // namespace nb
+
+#ifdef NB_ANCHOR_PROF
+extern "C" int nb_debug_anchor_prof(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(nb::g_anchor_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(nb::g_anchor_prof), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif

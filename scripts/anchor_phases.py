@@ -1,0 +1,39 @@
+"""Phase clock of the anchor-extend kernel (tuning aid; run on the GPU box):
+    NB_EXTRA_HIPCC_FLAGS=-DNB_ANCHOR_PROF python scripts/anchor_phases.py [reads]
+builds the library with the phase counters compiled in (the default build has none), maps one c2-shaped batch and prints the share of
+wave-cycles per phase: stage, probes (+ stream_rc), walk rounds, other-strand scan, decide, intern, outputs/lists."""
+import ctypes as ct
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nimble_amd import _build, _lib, engine, synth  # noqa: E402
+
+_build.build(force=True)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+names, seqs, _ = synth.synth_library(20, 50)
+strs = [synth.codes_to_str(s) for s in seqs]
+dev = torch.device("cuda:0")
+reads = synth.synth_reads_packed_torch(seqs, n, 150, 2, dev)
+ix = engine.Index(strs, 20)
+ctx = engine.Context(0, max_classes=1 << 20)
+ctx.upload(ix)
+cfg = engine.make_config()
+oc = torch.empty(n, dtype=torch.int32, device=dev); oi = torch.empty(n, dtype=torch.int32, device=dev)
+L = _lib.lib()
+fn = L.nb_debug_anchor_prof
+fn.restype = ct.c_int; fn.argtypes = [ct.POINTER(ct.c_ulonglong)]
+buf = (ct.c_ulonglong * 16)()
+for it in range(3):
+    ctx.reset()
+    ctx.align_batch(cfg, reads, None, 150, oc, oi, None, n=n)
+    ctx.sync()
+    assert fn(buf) == 0
+v = np.array(list(buf), dtype=np.float64)
+tot = v[:7].sum()
+for name, x in zip(("stage", "probes+rc", "rounds", "other-strand scan", "decide", "intern", "outputs+lists"), v[:7]):
+    print(f"{name:20s} {100 * x / tot:6.2f} %   {x / max(v[9], 1):10.0f} cycles per wave-batch")
+print(f"rounds per wave-batch: {v[8] / max(v[9], 1):.1f}; wave-batches: {int(v[9])}; kernels: {ctx.last_kernels()}")

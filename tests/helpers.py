@@ -23,7 +23,7 @@ def run_gpu(index, cfg, words, lens, max_len, max_classes=1 << 16, device=0, mat
                     mate_max_len=mate_max_len, n=n)
     ctx.sync()
     rows, counts = ctx.classes()
-    res = {"class": out_class.cpu().numpy().view(np.uint32), "rows": rows, "counts": counts, "reasons": ctx.reasons()}
+    res = {"class": out_class.cpu().numpy().view(np.uint32), "rows": rows, "counts": counts, "reasons": ctx.reasons(), "kernels": ctx.last_kernels()}
     res.update(engine.decode_info(out_info.cpu().numpy().view(np.uint32)))
     res["cov"] = engine.decode_cov(out_cov.cpu().numpy().view(np.uint64))
     W = index.words

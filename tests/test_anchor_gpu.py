@@ -1,0 +1,131 @@
+"""The anchor-extend kernel (csrc/nb_anchor.hip) against the oracle on the inputs that stress what is new in it: the walk follows the
+concatenated library TEXT from an anchor instead of looking every k-mer up, so the cases are the places where text and graph differ —
+sequence ends inside the text, N in library sequences, k-mers that occur twice in one sequence, identical sequences, runs longer than
+the sparse table's 255 positions, reads that change allele at every variant, k-mers on both strands next to a run — plus the shapes of
+the per-lane record in LDS (every read length mod 32, both orientations, N at every offset). Bit-exact, tolerance zero."""
+import numpy as np
+import pytest
+
+from nimble_amd import engine, synth
+from tests.helpers import assert_same, library_strings, run_gpu
+
+pytestmark = pytest.mark.gpu
+COMP = str.maketrans("ACGTN", "TGCAN")
+
+
+def rc(s):
+    return s.translate(COMP)[::-1]
+
+
+def _check(strs, k, reads, max_len, what, cfg=None, expect_anchor=True):
+    from oracle import oracle
+    cfg = cfg or engine.make_config(k=k)
+    words, lens = engine.pack_reads(reads, max_len)
+    gpu = run_gpu(engine.Index(strs, k), cfg, words, lens, max_len)
+    assert any(name.startswith("nb_anchor_kernel") for name in gpu["kernels"]) == expect_anchor, gpu["kernels"]
+    ora = oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=8)
+    assert_same(gpu, ora, what)
+    return ora
+
+
+def test_text_boundaries_and_long_runs(built):
+    """Reads that run off the end of one sequence into the next one of the text, across an N of the library, along identical sequences,
+    and error-free reads of 320 positions (runs are cut at 254 steps and must resume exactly)."""
+    rng = np.random.default_rng(11)
+    _, _, strs, _ = library_strings(3, 5, locus_len=640, seed=41)
+    strs[3] = strs[3][:300] + "N" + strs[3][301:]
+    strs[6] = strs[5]                                        # two identical sequences
+    strs.append(strs[2][100:400])                            # a sequence that is a substring of another
+    reads = []
+    for a in range(len(strs) - 1):                           # the text holds strs[a] + strs[a + 1]: such a read follows the text, not the graph
+        for cut in (1, 19, 20, 21, 60, 150, 310):
+            reads.append(strs[a][-cut:] + strs[a + 1][:331 - cut])
+            reads.append(rc(reads[-1]))
+    for a in range(len(strs)):
+        s = strs[a]
+        for L in (331, 300, 256 + 19, 255 + 19, 254 + 19, 200):
+            if len(s) >= L:
+                o = int(rng.integers(0, len(s) - L + 1))
+                reads += [s[o:o + L], rc(s[o:o + L])]
+    reads += [strs[3][150:450], strs[3][282:320], strs[3][301:331], strs[3][200:301], rc(strs[3][250:350])]
+    ora = _check(strs, 20, reads, 331, "text boundaries / long runs")
+    assert (ora["reason"] == 0).sum() > 0.6 * len(reads) and (ora["reason"] == 5).sum() > 20
+
+
+def test_repeats_inside_sequences(built):
+    """k-mers that occur several times in ONE sequence (tandem repeats, a duplicated block): the anchor is the first occurrence, the read
+    may follow any of them."""
+    rng = np.random.default_rng(5)
+    unit = "".join("ACGT"[c] for c in rng.integers(0, 4, 37))
+    block = "".join("ACGT"[c] for c in rng.integers(0, 4, 90))
+    def rnd(n):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    strs = [rnd(80) + unit * 6 + rnd(100), rnd(60) + block + rnd(70) + block + rnd(50), rnd(50) + unit * 3 + rnd(40) + block[:60] + rnd(90),
+            "ACGT" * 60, "A" * 100 + rnd(100), rnd(300)]
+    reads = []
+    for s in strs:
+        for _ in range(60):
+            L = int(rng.integers(20, 181)); o = int(rng.integers(0, max(1, len(s) - L + 1)))
+            r = list(s[o:o + L])
+            for j in range(len(r)):
+                if rng.random() < 0.01:
+                    r[j] = "ACGTN"[rng.integers(0, 5)]
+            r = "".join(r)
+            reads.append(r if rng.random() < 0.5 else rc(r))
+    _check(strs, 20, reads, 180, "repeats")
+    _check(strs, 12, reads, 180, "repeats k=12", cfg=engine.make_config(k=12))
+
+
+def test_allele_switching_reads(built):
+    """Chimeric reads that take every other variant from a different allele of the locus: every run ends at an allele difference, the STEP
+    lookup succeeds and moves the anchor to another sequence; with errors and N on top."""
+    rng = np.random.default_rng(23)
+    _, seqs, strs, _ = library_strings(2, 30, locus_len=500, seed=77)
+    reads = []
+    for _ in range(1500):
+        locus = int(rng.integers(0, 2)); L = int(rng.integers(40, 151)); o = int(rng.integers(0, 500 - L + 1))
+        parts, pos = [], o
+        while pos < o + L:
+            a = locus * 30 + int(rng.integers(0, 30)); step = int(rng.integers(5, 60))
+            parts.append(strs[a][pos:min(pos + step, o + L)]); pos += step
+        r = list("".join(parts))
+        for j in range(len(r)):
+            x = rng.random()
+            if x < 0.006: r[j] = "ACGT"[rng.integers(0, 4)]
+            elif x < 0.008: r[j] = "N"
+        r = "".join(r)
+        reads.append(r if rng.random() < 0.5 else rc(r))
+    ora = _check(strs, 20, reads, 150, "allele switching")
+    assert 0.3 < (ora["reason"] == 0).mean()
+    for kw in (dict(discard_multiple_matches=True), dict(score_percent=0.8), dict(strand_filter="threeprime")):
+        _check(strs, 20, reads[:600], 150, f"allele switching {kw}", cfg=engine.make_config(**kw))
+
+
+def test_record_shapes(built):
+    """Every read length from k - 1 to 3 words of bases, both orientations, an N walking through the read: the in-place reverse complement
+    of the LDS record and the 32-base windows must be exact at every alignment."""
+    _, _, strs, _ = library_strings(2, 4, locus_len=300, seed=3)
+    reads = []
+    for L in range(19, 132):
+        s = strs[L % 8][(L * 7) % 100:(L * 7) % 100 + L]
+        reads += [s, rc(s)]
+        j = (L * 13) % L
+        t = s[:j] + "N" + s[j + 1:]
+        reads += [t, rc(t)]
+    _check(strs, 20, reads, 131, "record shapes")
+    _check(strs, 20, reads, 160, "record shapes, wider layout")
+
+
+def test_both_strand_kmers_next_to_runs(built):
+    """A library with a reverse-complemented block inside otherwise forward sequences: runs must stop in front of k-mers that occur on
+    both strands (room), and the reads that touch them go to the wave-per-read kernel."""
+    rng = np.random.default_rng(9)
+    _, _, strs, _ = library_strings(2, 5, locus_len=400, seed=13)
+    strs.append(strs[0][:150] + rc(strs[1][150:260]) + strs[0][260:])
+    strs.append(rc(strs[7][100:300]))
+    reads = []
+    for _ in range(1200):
+        a = int(rng.integers(0, len(strs))); L = int(rng.integers(30, 151)); o = int(rng.integers(0, max(1, len(strs[a]) - L + 1)))
+        r = strs[a][o:o + L]
+        reads.append(r if rng.random() < 0.5 else rc(r))
+    _check(strs, 20, reads, 150, "both strands next to runs")
