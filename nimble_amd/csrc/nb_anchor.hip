@@ -100,7 +100,7 @@ __device__ __forceinline__ Look anchor_lookup(const AnchorHead& h, const uint8_t
 }
 
 template <int NR>
-__global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
+__global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   uint8_t* s_pilots = s_dyn;
@@ -123,6 +123,17 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
   unsigned long long pacc[16] = {0};
 #endif
 
+  // the packed record of the NEXT batch is loaded into registers while this one is mapped (the reads stream from HBM exactly once)
+  constexpr int MAXW = 3 * NR + 2;               // words of a record whose k-mer positions fit NR mask words (max_len <= 64 NR + 30)
+  uint64_t nxt[MAXW];
+  auto fetch = [&](long long b) {
+    const long long i = b + lane;
+    const uint64_t* __restrict__ rp = h.reads + (size_t)(i < h.n ? i : 0) * h.stride;
+#pragma unroll
+    for (int j = 0; j < MAXW; ++j) nxt[j] = (j < nwb + nwn && i < h.n) ? rp[j] : 0ull;
+  };
+  fetch(((long long)blockIdx.x * wpb + wave) * 64);
+
   for (long long base = ((long long)blockIdx.x * wpb + wave) * 64; base < h.n; base += nwaves * 64) {
     const long long idx = base + lane;
     const bool active = idx < h.n;
@@ -133,13 +144,11 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
 #ifdef NB_ANCHOR_PROF
     long long tprof = clock64();
 #endif
-    {   // stage the record (this lane's column of LDS)
-      const uint64_t* __restrict__ rp = h.reads + (size_t)r * h.stride;
-      for (int j = 0; j < nwb + nwn; ++j) {
-        const uint64_t w = active ? rp[j] : 0ull;
-        R.at(2 * j) = (uint32_t)w; R.at(2 * j + 1) = (uint32_t)(w >> 32);
-      }
+    {   // stage the record (this lane's column of LDS), then start the loads of the next one
+#pragma unroll
+      for (int j = 0; j < MAXW; ++j) if (j < nwb + nwn) { R.at(2 * j) = (uint32_t)nxt[j]; R.at(2 * j + 1) = (uint32_t)(nxt[j] >> 32); }
       R.at(2 * (nwb + nwn)) = 0u; R.at(2 * (nwb + nwn) + 1) = 0u;
+      if (base + nwaves * 64 < h.n) fetch(base + nwaves * 64);
     }
     const int last = L - K;
     bool rcf = false;                            // stream = reverse complement of the read
@@ -177,16 +186,13 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
     int pos = 0, cov = 0;
     uint32_t lo = 0; uint64_t a0 = 0;
     uint32_t run_t = 0, run_pay = 0; int run_q = 0, steps = 0, maxsteps = 0;   // the run being followed: text position / payload of its first k-mer, ...
-    uint64_t pv0 = ~0ull, pv1 = ~0ull; uint32_t pw0 = 0; bool pend = false;     // class words of the last finished run: loaded, not yet waited for
-    auto apply_pending = [&]() {                 // (the AND is folded in one run later, so that the two sparse-table loads never stall a round)
-      if (pend) {
-        const uint64_t v = pv0 & pv1;
-        const bool first = !(fl & F_STARTED);
-        a0 = first ? v : ((pw0 == lo) ? (a0 & v) : 0ull);
-        lo = first ? pw0 : lo;
-        fl |= F_STARTED;
-        pend = false;
-      }
+    uint32_t p_t = 0, p_n = 0, p_w0 = 0;         // the last finished run, classes not yet fetched: its two sparse-table loads are issued
+                                                 // together with the lane's NEXT table lookup (one wait for both), or after the loop
+    auto fold = [&](uint64_t v, uint32_t w0) {
+      const bool first = !(fl & F_STARTED);
+      a0 = first ? v : ((w0 == lo) ? (a0 & v) : 0ull);
+      lo = first ? w0 : lo;
+      fl |= F_STARTED;
     };
     Mask<NR> cover;                             // positions whose status on BOTH strands is known: looked up, or inside a verified run
 #pragma unroll
@@ -202,8 +208,16 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         const uint32_t pb = (uint32_t)w & 3u;
         const uint64_t x = (step ? (w >> 2) : w) & kmask;
         const bool valid = act && (((step ? (nn >> 1) : nn) & nkmask) == 0);
+        const bool havep = act && p_n != 0u;
+        uint64_t s0 = ~0ull, s1 = ~0ull;
+        if (havep) {
+          const int lv = 31 - __builtin_clz(p_n);
+          const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + p_t;
+          s0 = sp[0]; s1 = sp[p_n - (1u << lv)];
+        }
         const Look k = anchor_lookup(h, s_pilots, x, valid);
         const uint32_t d = k.e.x ^ k.want, pay = k.e.y;
+        if (havep) { fold(s0 & s1, p_w0); p_n = 0u; }
         const bool found = valid && d < 4u, both = found && (d & 2u);
         const bool hS = found && !both && ((d & 1u) == (k.o ? 1u : 0u));
         fl |= (both ? F_HARD : 0u) | ((found && !both && !hS) ? F_OPP : 0u);
@@ -216,7 +230,8 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
           maxsteps = room < rem ? room : rem;
           mode = EXT;
         } else if (act) {
-          set_range<NR>(cover, q, q);
+#pragma unroll
+          for (int wi = 0; wi < NR; ++wi) cover.w[wi] |= ((q >> 6) == wi) ? (1ull << (q & 63)) : 0ull;
           if (step) mode = pos > last ? DONE : SEEK;                          // the walk broke at base pos: seed scan from there (SPEC §3)
           else { pos += 3; mode = pos > last ? DONE : SEEK; }
         }
@@ -242,11 +257,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         }
         if (fin) {                                                            // the run [run_q, run_q + steps] is complete
           cov += ((fl & F_STEP) ? 1 : K) + steps;
-          const uint32_t n = (uint32_t)steps + 1u;
-          const int lv = 31 - __builtin_clz(n);
-          const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + run_t;
-          apply_pending();
-          pv0 = sp[0]; pv1 = sp[n - (1u << lv)]; pw0 = run_pay >> 11; pend = true;
+          p_t = run_t; p_n = (uint32_t)steps + 1u; p_w0 = run_pay >> 11;
           fl |= (run_pay & (1u << 10)) ? F_SLOW : 0u;
           set_range<NR>(cover, run_q, run_q + steps);
           pos = run_q + K + steps;                                            // the base the run stopped at
@@ -256,7 +267,16 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
       if (++rounds > 6 * h.max_len + 16) { fl |= (mode != DONE) ? F_ERR : 0u; mode = DONE; }   // (cannot happen: every round advances a lane; an exit every wave reaches)
     }
 
-    apply_pending();
+    if (__ballot(p_n != 0u)) {
+      uint64_t s0 = ~0ull, s1 = ~0ull;
+      const bool havep = p_n != 0u;
+      if (havep) {
+        const int lv = 31 - __builtin_clz(p_n);
+        const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + p_t;
+        s0 = sp[0]; s1 = sp[p_n - (1u << lv)];
+        fold(s0 & s1, p_w0);
+      }
+    }
     PROF_MARK(2); PROF_COUNT(8, rounds); PROF_COUNT(9, 1);
 
     // ---- the other orientation: does any of ITS seed-scan positions hit? (stream positions p = last, last - 3, ... not yet known) ----
@@ -273,9 +293,10 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         todo.w[wi] = need ? m : 0ull;
       }
       while (__ballot(any_set<NR>(todo))) {
-        Look kk[4]; bool vv[4];
+        constexpr int U = 8;
+        Look kk[U]; bool vv[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           int p = -1;
 #pragma unroll
           for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
           kk[u] = anchor_lookup(h, s_pilots, w & kmask, vv[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           const uint32_t d = kk[u].e.x ^ kk[u].want;
           const bool found = vv[u] && d < 4u;
           const bool mine = found && !(d & 2u) && ((d & 1u) == (kk[u].o ? 1u : 0u));
@@ -323,9 +344,25 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
       }
     } else if (active && !to_scan) { final_ = true; if (a.out_cov) a.out_cov[r] = 0ull; }
     PROF_MARK(4);
-    cls = intern_lane(T.ct, T.W, call, lo, a0);
+    // equal result sets inside the wave are interned and counted once: with real data most reads of a batch map to a few classes, and 64
+    // lanes adding to one counter serialise in the L2 (a handful of leader rounds; whoever is left after them goes alone)
+    uint32_t leader = (uint32_t)lane, mult = call ? 1u : 0u;
+    bool lead = call;
+    {
+      uint64_t pendm = __ballot(call);
+      for (int it = 0; it < 6 && pendm; ++it) {
+        const int ld = __builtin_ctzll(pendm);
+        const uint32_t va_lo = __builtin_amdgcn_readlane((uint32_t)a0, ld), va_hi = __builtin_amdgcn_readlane((uint32_t)(a0 >> 32), ld);
+        const uint32_t vl = __builtin_amdgcn_readlane(lo, ld);
+        const uint64_t same = __ballot(call && (uint32_t)a0 == va_lo && (uint32_t)(a0 >> 32) == va_hi && lo == vl) & pendm;
+        if ((same >> lane) & 1ull) { leader = (uint32_t)ld; lead = lane == ld; mult = lane == ld ? (uint32_t)__popcll(same) : 0u; }
+        pendm &= ~same;
+      }
+    }
+    cls = intern_lane(T.ct, T.W, lead, lo, a0);
+    cls = (uint32_t)__shfl((int)cls, (int)leader);
     PROF_MARK(5);
-    if (call && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], 1ull);
+    if (lead && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], (unsigned long long)mult);
     if (active && final_) {
       atomicAdd(&s_reason[reason], 1u);
       if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
@@ -358,7 +395,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
 // The reads none of whose three probes was in the table (ll.rc_list): every seed-scan position of BOTH orientations is looked up, all lanes
 // in lock-step, four lookups in flight per lane. No k-mer found at all: NO_HIT in both orientations, final. Anything found: redo list.
 template <int NR>
-__global__ __launch_bounds__(1024) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
+__global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_nohit;
   uint8_t* s_pilots = s_dyn;
@@ -448,8 +485,8 @@ static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_blo
   const int nwb = (max_len + 31) / 32, nwn = (max_len + 63) / 64;
   const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4, pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
   const int64_t budget = (160 << 10) - 256;
-  int w = 16;
-  if (const char* e = std::getenv("NB_ANCHOR_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) w = v; }
+  int w = 12;                                  // (measured on c2: 8 / 10 / 12 waves 5.2 / 4.8 / 4.4 ms; 16 waves with a smaller first level 4.5 ms)
+  if (const char* e = std::getenv("NB_ANCHOR_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 12) w = v; }
   while (w > 0 && pil + (int64_t)w * rec > budget) --w;
   if (w < 8) return 0;
   if (waves_per_block) *waves_per_block = w;

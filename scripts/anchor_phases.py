@@ -14,7 +14,8 @@ from nimble_amd import _build, _lib, engine, synth  # noqa: E402
 
 _build.build(force=True)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-names, seqs, _ = synth.synth_library(20, 50)
+loci, alleles = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (20, 50)
+names, seqs, _ = synth.synth_library(loci, alleles)
 strs = [synth.codes_to_str(s) for s in seqs]
 dev = torch.device("cuda:0")
 reads = synth.synth_reads_packed_torch(seqs, n, 150, 2, dev)
@@ -29,9 +30,13 @@ fn.restype = ct.c_int; fn.argtypes = [ct.POINTER(ct.c_ulonglong)]
 buf = (ct.c_ulonglong * 16)()
 for it in range(3):
     ctx.reset()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
     ctx.align_batch(cfg, reads, None, 150, oc, oi, None, n=n)
+    t1.record()
     ctx.sync()
     assert fn(buf) == 0
+print(f"batch: {t0.elapsed_time(t1):.3f} ms (all kernels, instrumented build)")
 v = np.array(list(buf), dtype=np.float64)
 tot = v[:7].sum()
 for name, x in zip(("stage", "probes+rc", "rounds", "other-strand scan", "decide", "intern", "outputs+lists"), v[:7]):
