@@ -269,7 +269,9 @@ def main():
             t = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
-        if (t.get("reads_per_gpu"), t.get("read_len"), t.get("n_seqs"), t.get("k")) == (n, L, len(strs), args.k) and "traffic_bytes_per_launch" in t:
+        # (counters of ANOTHER kernel say nothing about this run: the profile must be of the kernel that ran here)
+        if (t.get("reads_per_gpu"), t.get("read_len"), t.get("n_seqs"), t.get("k"), t.get("kernel")) == (n, L, len(strs), args.k, ctx.last_kernels()[0]) \
+                and "traffic_bytes_per_launch" in t:
             traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.basename(f)
             miss_requests = t.get("TCC_MISS_sum")
             l2_requests = t.get("TCP_TCC_READ_REQ_sum")
@@ -340,7 +342,7 @@ def main():
         # (profiles/r02_gather_microbench.jsonl: 264 G requests/s from a 3 MB L2-resident table, 61 G from 49 MB in the Infinity Cache,
         # 55 G from 446 MB in HBM). achieved = L1->L2 read requests of the kernel (TCP_TCC_READ_REQ_sum of the committed PMC pass) / time.
         "secondary_roofline": secondary_roofline(l2_requests, miss_requests,
-                                                 (stats["ph_table_bytes"] if ctx.last_kernels()[0].startswith("nb_lane") else stats["table_bytes"]) / 1e6, avg_kernel_s, n),
+                                                 (stats["ph_table_bytes"] if ctx.last_kernels()[0].startswith(("nb_lane", "nb_anchor")) else stats["table_bytes"]) / 1e6, avg_kernel_s, n),
         # what binds the kernel (profiles/r01_tuning_notes.md): instruction issue. Instructions issued per read (SQ counters of the
         # committed PMC pass) against the issue slots a SIMD has per read at this occupancy: above 1.0 = ports saturated.
         "issue": ({"instructions_per_read": sq["SQ_ACTIVE_INST_ANY"], "valu": sq["SQ_INSTS_VALU"], "salu": sq["SQ_INSTS_SALU"], "vmem": sq["SQ_INSTS_VMEM"],

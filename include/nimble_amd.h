@@ -115,8 +115,9 @@ int32_t nb_index_query(const nb_index* index, const char* kmer_ascii, uint8_t* l
                        uint8_t* l_internal, uint64_t* colour_bits);
 /* host query of the anchor structures (csrc/nb_internal.h, AEntry) for one stranded k-mer: returns 1 and fills the text position of its
  * anchor occurrence, `room` (steps the walk may take along the text from there) and, in colour_and (words_per_row u64, original sequence
- * numbering), the AND of the classes of the k-mers at text positions [tpos, tpos + min(run, room)]; 0 if the k-mer is absent on this strand,
- * occurs on both strands or the index has no anchor structures. Used by index-parity tests. */
+ * numbering), the AND of the classes of the k-mers at text positions [tpos, tpos + min(run, room)]; 2 (tpos and room only) if the anchor
+ * sequence belongs to a component wider than the sparse table's entries (such reads are mapped by the wave-per-read kernel); 0 if the
+ * k-mer is absent on this strand, occurs on both strands or the index has no anchor structures. Used by index-parity tests. */
 int32_t nb_index_anchor_query(const nb_index* index, const char* kmer_ascii, int32_t run, int64_t* tpos, int32_t* room, uint64_t* colour_and);
 /* copy the index into HBM of ctx's GPU and bind it to ctx */
 int32_t nb_index_upload(nb_ctx* ctx, nb_index* index);

@@ -31,6 +31,7 @@ struct AnchorHead {
   const uint64_t* reads; const uint16_t* lens; int max_len, stride, nwb;
   long long n;
   int pilot_lds_bytes, rec_dwords;                   // dynamic LDS: [pilots][per wave: rec_dwords x 64 dwords]
+  long long text_words, sparse_words; int W;         // sizes, for the bounds-checked debug build (-DNB_ANCHOR_PROF -DNB_ANCHOR_CHECK)
 };
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
@@ -39,9 +40,15 @@ struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
 __device__ unsigned long long g_anchor_prof[16];
 #define PROF_MARK(slot) do { const long long t_ = clock64(); pacc[slot] += (unsigned long long)(t_ - tprof); tprof = t_; } while (0)
 #define PROF_COUNT(slot, v) do { pacc[slot] += (unsigned long long)(v); } while (0)
+#ifdef NB_ANCHOR_CHECK   // every computed index is compared with its array's size; a violation is counted (slots 10..15) and the access redirected to element 0
+#define CHK(ok, slot) ((ok) ? true : (atomicAdd(&g_anchor_prof[slot], 1ull), false))
+#endif
 #else
 #define PROF_MARK(slot) do {} while (0)
 #define PROF_COUNT(slot, v) do {} while (0)
+#endif
+#ifndef CHK
+#define CHK(ok, slot) (true)
 #endif
 
 
@@ -50,7 +57,7 @@ __device__ unsigned long long g_anchor_prof[16];
 // of the read, so that every later access is a plain forward window whatever the orientation.
 struct Rec {
   uint32_t* col; int nbd, nd, L;
-  __device__ __forceinline__ uint32_t& at(int j) const { return col[j * 64]; }
+  __device__ __forceinline__ uint32_t& at(int j) const { return col[(CHK(j >= 0 && j < nbd + nd + 2, 15) ? j : 0) * 64]; }
   // 32 stream bases from position q (2 bits each, first base at bit 0) and their N-or-beyond-the-read bits
   __device__ __forceinline__ void get32(int q, uint64_t& win, uint32_t& nwin) const {
     const int j = q >> 4; const uint32_t sh = 2u * ((uint32_t)q & 15u);
@@ -90,16 +97,22 @@ struct Rec {
 };
 
 struct Look { uint4 e; uint32_t want; bool o; };
+// PLDS: the first level of the table was staged in LDS by the workgroup; otherwise it is read from global memory (L2-resident)
+template <bool PLDS>
 __device__ __forceinline__ Look anchor_lookup(const AnchorHead& h, const uint8_t* s_pilots, uint64_t x, bool valid) {
   const uint64_t y = rc_kmer(x, h.K);
   Look k; k.o = x > y;
   const PHProbe pr = ph_probe(k.o ? y : x, h.ph);
   k.want = pr.want;
-  k.e = *reinterpret_cast<const uint4*>(&h.table[valid ? ph_slot(pr, (uint32_t)s_pilots[pr.group], h.ph) : 0u]);
+  const bool gok = CHK(pr.group < h.ph.n_groups, 10);
+  const uint32_t pilot = PLDS ? (uint32_t)s_pilots[gok ? pr.group : 0u] : ((valid && gok) ? (uint32_t)h.pilots[pr.group] : 0u);
+  uint32_t slot = valid ? ph_slot(pr, pilot, h.ph) : 0u;
+  if (!CHK(slot < h.ph.n_slots, 11)) slot = 0u;
+  k.e = *reinterpret_cast<const uint4*>(&h.table[slot]);
   return k;
 }
 
-template <int NR>
+template <int NR, int NW, bool PLDS>
 __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
@@ -109,8 +122,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
   const int wpb = (int)(blockDim.x >> 6);
   uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
-  for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
-    *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
+  if (PLDS)
+    for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
+      *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
   __syncthreads();
   const long long nwaves = (long long)gridDim.x * wpb;
   const int K = h.K;
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         const int p = u == 0 ? 0 : (u == 1 ? last >> 1 : last);
         uint64_t w; uint32_t nn; R.get32(p, w, nn);
         pv[u] = (nn & nkmask) == 0;
-        pk[u] = anchor_lookup(h, s_pilots, w & kmask, pv[u]);
+        pk[u] = anchor_lookup<PLDS>(h, s_pilots, w & kmask, pv[u]);
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
@@ -184,15 +198,29 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     constexpr int SEEK = 0, STEP = 1, EXT = 2, DONE = 3;
     int mode = (active && last >= 0 && !to_scan) ? SEEK : DONE;
     int pos = 0, cov = 0;
-    uint32_t lo = 0; uint64_t a0 = 0;
-    uint32_t run_t = 0, run_pay = 0; int run_q = 0, steps = 0, maxsteps = 0;   // the run being followed: text position / payload of its first k-mer, ...
+    uint32_t lo = 0; uint64_t a0 = 0, a1 = 0;   // the running AND of the classes: NW words from class-row word lo
+    uint32_t run_t = 0, run_w0 = 0; int run_q = 0, steps = 0, maxsteps = 0;   // the run being followed: text position / payload of its first k-mer, ...
     uint32_t p_t = 0, p_n = 0, p_w0 = 0;         // the last finished run, classes not yet fetched: its two sparse-table loads are issued
                                                  // together with the lane's NEXT table lookup (one wait for both), or after the loop
-    auto fold = [&](uint64_t v, uint32_t w0) {
+    auto fold = [&](uint64_t v0, uint64_t v1, uint32_t w0) {
       const bool first = !(fl & F_STARTED);
-      a0 = first ? v : ((w0 == lo) ? (a0 & v) : 0ull);
+      a0 = first ? v0 : ((w0 == lo) ? (a0 & v0) : 0ull);
+      if (NW > 1) a1 = first ? v1 : ((w0 == lo) ? (a1 & v1) : 0ull);
       lo = first ? w0 : lo;
       fl |= F_STARTED;
+    };
+    // AND of the classes of the text k-mers [t, t + n): two overlapping power-of-two blocks of the sparse table
+    auto range_and = [&](uint32_t t, uint32_t n, uint64_t& v0, uint64_t& v1) {   // (t by value: the checked build redirects it)
+      const int lv = 31 - __builtin_clz(n);
+      uint32_t off = n - (1u << lv);
+      if (!CHK(n >= 1u && n < 256u && ((long long)lv * h.T + t + off + 1) * NW <= h.sparse_words, 13)) { t = 0u; off = 0u; }
+      const uint64_t* sp = h.sparse + ((size_t)(n >= 1u && n < 256u ? lv : 0) * (size_t)h.T + t) * NW;
+      if (NW == 1) { v0 = sp[0] & sp[off]; v1 = 0ull; }
+      else {
+        const uint4 x = *reinterpret_cast<const uint4*>(sp), y = *reinterpret_cast<const uint4*>(sp + 2 * (size_t)off);
+        v0 = (((uint64_t)x.y << 32) | x.x) & (((uint64_t)y.y << 32) | y.x);
+        v1 = (((uint64_t)x.w << 32) | x.z) & (((uint64_t)y.w << 32) | y.z);
+      }
     };
     Mask<NR> cover;                             // positions whose status on BOTH strands is known: looked up, or inside a verified run
 #pragma unroll
@@ -210,14 +238,10 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         const bool valid = act && (((step ? (nn >> 1) : nn) & nkmask) == 0);
         const bool havep = act && p_n != 0u;
         uint64_t s0 = ~0ull, s1 = ~0ull;
-        if (havep) {
-          const int lv = 31 - __builtin_clz(p_n);
-          const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + p_t;
-          s0 = sp[0]; s1 = sp[p_n - (1u << lv)];
-        }
-        const Look k = anchor_lookup(h, s_pilots, x, valid);
+        if (havep) range_and(p_t, p_n, s0, s1);
+        const Look k = anchor_lookup<PLDS>(h, s_pilots, x, valid);
         const uint32_t d = k.e.x ^ k.want, pay = k.e.y;
-        if (havep) { fold(s0 & s1, p_w0); p_n = 0u; }
+        if (havep) { fold(s0, s1, p_w0); p_n = 0u; }
         const bool found = valid && d < 4u, both = found && (d & 2u);
         const bool hS = found && !both && ((d & 1u) == (k.o ? 1u : 0u));
         fl |= (both ? F_HARD : 0u) | ((found && !both && !hS) ? F_OPP : 0u);
@@ -225,8 +249,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         if (ok) {
           if (!step && !(fl & F_SEEDED) && q >= L5 && q > 0) fl |= F_LEXT;    // the first seed may have a left extension: wave-per-read kernel
           fl = (fl & ~F_STEP) | (step ? F_STEP : 0u) | F_SEEDED;
-          run_t = k.e.z; run_pay = pay; run_q = q; steps = 0;
-          const int room = (int)(k.e.w & 0xFFFFu), rem = L - (q + K);
+          run_t = k.e.z; run_w0 = k.e.w >> 16; run_q = q; steps = 0;
+          fl |= (k.e.w & ANCHOR_WIDE) ? F_SLOW : 0u;                          // a component wider than the sparse table's entries: wave-per-read kernel
+          const int room = (int)(k.e.w & 0xFFu), rem = L - (q + K);
           maxsteps = room < rem ? room : rem;
           mode = EXT;
         } else if (act) {
@@ -241,7 +266,8 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         bool fin = ex;
         if (ex && steps < maxsteps) {
           uint64_t sw; uint32_t sn; R.get32(run_q + K + steps, sw, sn);
-          const uint32_t tb = run_t + (uint32_t)(K + steps);
+          uint32_t tb = run_t + (uint32_t)(K + steps);
+          if (!CHK((long long)(tb >> 4) + 3 <= h.text_words, 12)) tb = 0u;
           const U3 tw3 = *reinterpret_cast<const U3*>(h.text + (tb >> 4));
           const uint32_t sh = 2u * (tb & 15u);
           const uint64_t t01 = ((uint64_t)tw3.b << 32) | tw3.a;
@@ -257,8 +283,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         }
         if (fin) {                                                            // the run [run_q, run_q + steps] is complete
           cov += ((fl & F_STEP) ? 1 : K) + steps;
-          p_t = run_t; p_n = (uint32_t)steps + 1u; p_w0 = run_pay >> 11;
-          fl |= (run_pay & (1u << 10)) ? F_SLOW : 0u;
+          p_t = run_t; p_n = (uint32_t)steps + 1u; p_w0 = run_w0;
           set_range<NR>(cover, run_q, run_q + steps);
           pos = run_q + K + steps;                                            // the base the run stopped at
           mode = pos >= L ? DONE : STEP;
@@ -269,13 +294,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
 
     if (__ballot(p_n != 0u)) {
       uint64_t s0 = ~0ull, s1 = ~0ull;
-      const bool havep = p_n != 0u;
-      if (havep) {
-        const int lv = 31 - __builtin_clz(p_n);
-        const uint64_t* sp = h.sparse + (size_t)lv * (size_t)h.T + p_t;
-        s0 = sp[0]; s1 = sp[p_n - (1u << lv)];
-        fold(s0 & s1, p_w0);
-      }
+      if (p_n != 0u) { range_and(p_t, p_n, s0, s1); fold(s0, s1, p_w0); }
     }
     PROF_MARK(2); PROF_COUNT(8, rounds); PROF_COUNT(9, 1);
 
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
           for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
           uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
           vv[u] = p >= 0 && (nn & nkmask) == 0;
-          kk[u] = anchor_lookup(h, s_pilots, w & kmask, vv[u]);
+          kk[u] = anchor_lookup<PLDS>(h, s_pilots, w & kmask, vv[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         final_ = true;                                                        // the other orientation has no hit: its coverage is 0 (NO_HIT)
         if (a.out_cov) a.out_cov[r] = rcf ? ((uint64_t)(cov & 0xFFFF) << 16) : (uint64_t)(cov & 0xFFFF);
         const int cheapS = cheap_reason_p(cov, pmin, a);
-        const uint32_t n = (uint32_t)__popcll(a0);
+        const uint32_t n = (uint32_t)__popcll(a0) + (NW > 1 ? (uint32_t)__popcll(a1) : 0u);
         int rs = 0;
         if (cheapS != 0) rs = cheapS;
         else if (n == 0) rs = NB_EMPTY_EQCLASS;
@@ -354,12 +373,15 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         const int ld = __builtin_ctzll(pendm);
         const uint32_t va_lo = __builtin_amdgcn_readlane((uint32_t)a0, ld), va_hi = __builtin_amdgcn_readlane((uint32_t)(a0 >> 32), ld);
         const uint32_t vl = __builtin_amdgcn_readlane(lo, ld);
-        const uint64_t same = __ballot(call && (uint32_t)a0 == va_lo && (uint32_t)(a0 >> 32) == va_hi && lo == vl) & pendm;
+        bool eq = call && (uint32_t)a0 == va_lo && (uint32_t)(a0 >> 32) == va_hi && lo == vl;
+        if (NW > 1) eq = eq && (uint32_t)a1 == (uint32_t)__builtin_amdgcn_readlane((uint32_t)a1, ld) && (uint32_t)(a1 >> 32) == (uint32_t)__builtin_amdgcn_readlane((uint32_t)(a1 >> 32), ld);
+        const uint64_t same = __ballot(eq) & pendm;
         if ((same >> lane) & 1ull) { leader = (uint32_t)ld; lead = lane == ld; mult = lane == ld ? (uint32_t)__popcll(same) : 0u; }
         pendm &= ~same;
       }
     }
-    cls = intern_lane(T.ct, T.W, lead, lo, a0);
+    if (lead && !CHK(lo < (uint32_t)T.W && (!(NW > 1 && a1) || lo + 1u < (uint32_t)T.W), 14)) lead = false;
+    cls = intern_lane2(T.ct, T.W, lead, lo, a0, NW > 1 ? a1 : 0ull);
     cls = (uint32_t)__shfl((int)cls, (int)leader);
     PROF_MARK(5);
     if (lead && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], (unsigned long long)mult);
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
 
 // The reads none of whose three probes was in the table (ll.rc_list): every seed-scan position of BOTH orientations is looked up, all lanes
 // in lock-step, four lookups in flight per lane. No k-mer found at all: NO_HIT in both orientations, final. Anything found: redo list.
-template <int NR>
+template <int NR, bool PLDS>
 __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_nohit;
@@ -406,7 +428,7 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
   const LaneTail& T = *tp;
   const long long count = (long long)T.ll.counters[0];
   if (threadIdx.x == 0) s_nohit = 0;
-  if (count > 0)
+  if (PLDS && count > 0)
     for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
       *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
   __syncthreads();
@@ -451,7 +473,7 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
         for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
         uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
         vv[u] = p >= 0 && (nn & nkmask) == 0;
-        kk[u] = anchor_lookup(h, s_pilots, w & kmask, vv[u]);
+        kk[u] = anchor_lookup<PLDS>(h, s_pilots, w & kmask, vv[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) hit = hit || (vv[u] && ((kk[u].e.x ^ kk[u].want) < 4u));
@@ -479,37 +501,50 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
   if (threadIdx.x == 0 && s_nohit) atomicAdd(&tp->ct.reasons[NB_NO_HIT], (unsigned long long)s_nohit);
 }
 
-// dynamic LDS of one workgroup: first level of the table + record staging of up to 16 waves (the kernels need ~65 VGPRs: the LDS is
-// what limits the waves per CU, and the walk is a chain of dependent loads, i.e. it runs at waves in flight / latency)
-static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block) {
+// dynamic LDS of one workgroup: first level of the table (if it fits next to >= 8 waves of records: *plds) + record staging of up to 12
+// waves (the kernels need ~115 VGPRs; 16 waves bought nothing: the walk is bound by the SIMDs' issue rate, profiles/r02_tuning_notes.md)
+static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block, bool* plds) {
   const int nwb = (max_len + 31) / 32, nwn = (max_len + 63) / 64;
-  const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4, pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
+  const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4;
+  int64_t pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
   const int64_t budget = (160 << 10) - 256;
+  *plds = pil + 8 * rec <= budget;
+  if (!*plds) pil = 0;
   int w = 12;                                  // (measured on c2: 8 / 10 / 12 waves 5.2 / 4.8 / 4.4 ms; 16 waves with a smaller first level 4.5 ms)
   if (const char* e = std::getenv("NB_ANCHOR_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 12) w = v; }
   while (w > 0 && pil + (int64_t)w * rec > budget) --w;
-  if (w < 8) return 0;
+  if (w < 4) return 0;
   if (waves_per_block) *waves_per_block = w;
   return pil + (int64_t)w * rec;
 }
 
-template <int NR>
+template <int NR, int NW, bool PLDS>
 static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
-  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
   const long long need = (h.n + 64LL * waves - 1) / (64LL * waves);
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL((nb_anchor_kernel<NR>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
+  hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
   NB_HIP(hipGetLastError());
-  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (list length: on the device)
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR, PLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, PLDS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (list length: on the device)
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
+template <int NR>
+static int launch_anchor_n(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, bool plds, hipStream_t s) {
+  if (c->anchor_nw == 1) return plds ? launch_anchor_t<NR, 1, true>(c, h, d_tail, waves, lds, s) : launch_anchor_t<NR, 1, false>(c, h, d_tail, waves, lds, s);
+  return plds ? launch_anchor_t<NR, 2, true>(c, h, d_tail, waves, lds, s) : launch_anchor_t<NR, 2, false>(c, h, d_tail, waves, lds, s);
+}
+
+bool anchor_fits(const nb_ctx* c, int max_len) {
+  int w = 0; bool plds = false;
+  return c->has_anchor && anchor_lds_bytes(c, max_len, &w, &plds) > 0;
+}
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
-  int waves = 0;
-  const int64_t lds = anchor_lds_bytes(c, a.max_len, &waves);
+  int waves = 0; bool plds = false;
+  const int64_t lds = anchor_lds_bytes(c, a.max_len, &waves, &plds);
   if (lds <= 0 || !c->has_anchor) { set_error("launch_anchor: shape does not fit"); return NB_ERR_UNSUPPORTED; }
   NB_HIP(hipMemsetAsync(ll.counters, 0, 8, s));
   if (!c->d_lane_tail) NB_HIP(hipMalloc((void**)&c->d_lane_tail, sizeof(LaneTail)));
@@ -517,14 +552,15 @@ int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, con
   NB_HIP(hipMemcpyAsync(c->d_lane_tail, &t, sizeof t, hipMemcpyHostToDevice, s));
   const int nwn = (a.nwb + 1) >> 1;
   AnchorHead h{c->d_atable, c->d_ph_pilots, c->ph, ix.K, c->d_text, c->d_sparse, c->text_len, a.reads, a.lens, a.max_len, a.stride, a.nwb, a.n,
-               (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16), 2 * (a.nwb + nwn) + 2};
+               plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (a.nwb + nwn) + 2,
+               (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, ix.W};
   const LaneTail* dt = (const LaneTail*)c->d_lane_tail;
   switch (nr) {
-    case 1: return launch_anchor_t<1>(c, h, dt, waves, lds, s);
-    case 2: return launch_anchor_t<2>(c, h, dt, waves, lds, s);
-    case 3: return launch_anchor_t<3>(c, h, dt, waves, lds, s);
-    case 4: return launch_anchor_t<4>(c, h, dt, waves, lds, s);
-    default: return launch_anchor_t<5>(c, h, dt, waves, lds, s);
+    case 1: return launch_anchor_n<1>(c, h, dt, waves, lds, plds, s);
+    case 2: return launch_anchor_n<2>(c, h, dt, waves, lds, plds, s);
+    case 3: return launch_anchor_n<3>(c, h, dt, waves, lds, plds, s);
+    case 4: return launch_anchor_n<4>(c, h, dt, waves, lds, plds, s);
+    default: return launch_anchor_n<5>(c, h, dt, waves, lds, plds, s);
   }
 }
 

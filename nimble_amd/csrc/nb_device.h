@@ -262,11 +262,13 @@ struct LaneLists {
 struct LaneTail { DevClasses ct; BatchArgs a; LaneLists ll; int W; };
 
 #if defined(__HIPCC__)
-// per-lane interning of a one-word set {word index lo, bits a0} in the shared class table; returns the class id or NB_NO_CLASS.
-// Same table protocol as intern_class (nb_kernels.hip): key = content hash, full-content verification through (spans, word).
-__device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, bool want, uint32_t lo, uint64_t a0) {
-  const uint64_t hx = mix64(a0 ^ (0x9E3779B97F4A7C15ull * (uint64_t)(lo + 1u)));
+// per-lane interning of a set of at most two words {word index lo: a0, lo + 1: a1} in the shared class table; returns the class id or
+// NB_NO_CLASS. Same table protocol as intern_class (nb_kernels.hip): key = content hash (xor of one mixed word per non-zero (index, value)),
+// full-content verification through (spans, words).
+__device__ __forceinline__ uint32_t intern_lane2(const DevClasses& ct, int W, bool want, uint32_t lo, uint64_t a0, uint64_t a1) {
+  const uint64_t hx = (a0 ? mix64(a0 ^ (0x9E3779B97F4A7C15ull * (uint64_t)(lo + 1u))) : 0ull) ^ (a1 ? mix64(a1 ^ (0x9E3779B97F4A7C15ull * (uint64_t)(lo + 2u))) : 0ull);
   const uint64_t key = hx ? hx : 1ull;
+  const uint32_t span = (a0 ? lo : lo + 1u) | ((a1 ? lo + 1u : lo) << 16);
   const uint64_t smask = (1ull << ct.cap_log2) - 1;
   uint64_t h = (key * HASH_MULT) >> (64 - ct.cap_log2);
   uint32_t result = NB_NO_CLASS;
@@ -286,8 +288,8 @@ __device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, boo
             pending = false;
           } else {
             for (int w = 0; w < W; ++w)
-              __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)((uint32_t)w == lo ? a0 : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ct.spans[id], lo | (lo << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)((uint32_t)w == lo ? a0 : ((uint32_t)w == lo + 1u ? a1 : 0ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ct.spans[id], span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&ct.ids[h], id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -302,7 +304,8 @@ __device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, boo
           const uint32_t id = idp - 1u;
           const uint32_t sp = __hip_atomic_load(&ct.spans[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint64_t word = __hip_atomic_load(&ct.rows[(size_t)id * W + lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (sp == (lo | (lo << 16)) && word == a0) { result = id; pending = false; }
+          const uint64_t word1 = a1 ? __hip_atomic_load(&ct.rows[(size_t)id * W + lo + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          if (sp == span && word == a0 && word1 == a1) { result = id; pending = false; }
           else { h = (h + 1) & smask; ++probes; }     // a different set with the same 64-bit hash: keep probing
         }
         // idp == 0: the owner is still publishing: poll again in the next iteration
@@ -313,6 +316,7 @@ __device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, boo
   if (pending) atomicOr(ct.err, 2u);
   return result;
 }
+__device__ __forceinline__ uint32_t intern_lane(const DevClasses& ct, int W, bool want, uint32_t lo, uint64_t a0) { return intern_lane2(ct, W, want, lo, a0, 0ull); }
 
 #endif
 }  // namespace nb
@@ -321,6 +325,7 @@ struct nb_ctx;
 namespace nb {
 // nb_anchor.hip: the anchor-extend kernel (one launch; what it cannot finish exactly goes on ll.redo_list like the lane path's)
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
+bool anchor_fits(const nb_ctx* c, int max_len);
 // nb_lane.hip: both lane-per-read passes of one batch, then gather of the redo reads; nb_lane_scatter puts their results back
 int launch_lane(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
 int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block);   // 0 = the lane path does not fit this shape
@@ -343,7 +348,7 @@ struct nb_ctx {
   uint64_t* d_redo_reads = nullptr; int64_t redo_words_cap = 0; uint16_t* d_redo_lens = nullptr; uint32_t* d_redo_out = nullptr;   // gathered redo reads + their results (4 u32 per read)
   void* d_lane_tail = nullptr;     // LaneTail of the current batch (nb_lane.hip)
   nb::PHEntry* d_ph_table = nullptr; uint8_t* d_ph_pilots = nullptr; nb::PHash ph{}; bool has_ph = false;   // perfect-hash table of the lane kernels
-  nb::AEntry* d_atable = nullptr; uint32_t* d_text = nullptr; uint64_t* d_sparse = nullptr; long long text_len = 0; bool has_anchor = false;   // anchor structures (nb_anchor.hip)
+  nb::AEntry* d_atable = nullptr; uint32_t* d_text = nullptr; uint64_t* d_sparse = nullptr; long long text_len = 0; bool has_anchor = false; int anchor_nw = 1;   // anchor structures (nb_anchor.hip)
   std::string last_kernels;        // kernels launched by the last nb_align_batch (nb_last_kernel_names)   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
   // score_percent table
   uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0; std::vector<uint16_t> pct_host;

@@ -6,6 +6,7 @@
 // array is sorted, and colours / extension masks fall out of a single grouped pass. The result is the flat
 // canonical-k-mer table the kernels probe plus the colour bitset rows.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -171,11 +172,16 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       comps[(size_t)comp_of[r]].push_back((uint32_t)sidx);
     }
     ix->perm.assign((size_t)n_seqs, -1);
+    ix->comp_w0.assign((size_t)n_seqs, 0u);
+    ix->comp_nw.assign((size_t)n_seqs, 1u);
     int64_t bit = 0;
     for (const auto& comp : comps) {
       const int64_t sz = (int64_t)comp.size();
       if (sz > 64 || (bit & 63) + sz > 64) bit = (bit + 63) & ~63ll;
-      for (uint32_t sidx : comp) ix->perm[sidx] = (int32_t)bit++;
+      const uint32_t w0c = (uint32_t)(bit >> 6);
+      const int cw = (int)((bit + sz - 1) >> 6) - (int)w0c + 1;
+      ix->max_comp_words = std::max(ix->max_comp_words, cw);
+      for (uint32_t sidx : comp) { ix->perm[sidx] = (int32_t)bit++; ix->comp_w0[sidx] = w0c; ix->comp_nw[sidx] = (uint32_t)cw; }
     }
     ix->words_dev = (int)((bit + 63) >> 6);
     if (ix->words_dev < 1) ix->words_dev = 1;
@@ -303,90 +309,133 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     if (!done) { delete ix; set_error("nb_index_build: could not place the k-mers in the compact table"); return NB_ERR_UNSUPPORTED; }
     ix->hash = KmerHash{0, 0, 0};
 
-    // 5b. perfect-hash table of the lane-per-read kernels (nb_internal.h): hash and displace, one-byte pilots, groups keyed by rem
-    const char* ph_env = std::getenv("NB_PH");
-    if (ix->max_desc_nw == 1 && !(ph_env && ph_env[0] == '0')) {
-      const int64_t n = n_canon;
-      // groups: as many as the LDS budget of the first level allows, but not more than one per 2.5 k-mers (smaller groups fill the
-      // table higher: a group of s k-mers finds a free pilot among 256 only while (1 - fill)^s stays above a few per cent)
-      int64_t pilot_cap = PH_MAX_PILOT_BYTES;
-      if (const char* e = std::getenv("NB_PH_PILOT_KB")) { const int64_t v = std::atoll(e); if (v >= 1 && v <= 150) pilot_cap = v << 10; }
-      const int64_t G = std::max<int64_t>(1, std::min<int64_t>(pilot_cap, (int64_t)((double)n / 2.5)));
-      const double lambda = (double)n / (double)G;
-      for (double alpha = 0.95; alpha >= 0.55 && !ix->has_ph; alpha -= 0.02) {
-        const uint64_t N = std::max<uint64_t>({(uint64_t)((double)n / alpha) + 1, nb_min, 1024});
-        if ((int64_t)N * 16 > PH_MAX_TABLE_BYTES || N > 0x7FFFFFFFull || lambda > 16.0) break;
-        PHash h{}; h.a = ix->chash.a; h.c = ix->chash.c; h.n_slots = (uint32_t)N; h.n_groups = (uint32_t)G; h.hb = hb; h.himask = ix->chash.himask; h.stride = (uint32_t)(N >> (hb + 2));
-        if (h.stride >= (1u << 24) || hb + 2 > 16) break;                       // (24-bit multiply operands in ph_probe)
-        std::vector<PHProbe> pr((size_t)n);
-        std::vector<uint32_t> gcount((size_t)G + 1, 0);
-        for (int64_t i = 0; i < n; ++i) { pr[(size_t)i] = ph_probe(canons[(size_t)i].key, h); ++gcount[pr[(size_t)i].group + 1]; }
-        std::vector<uint32_t> gstart(gcount);
-        for (int64_t g = 0; g < G; ++g) gstart[(size_t)g + 1] += gstart[(size_t)g];
-        std::vector<uint32_t> members((size_t)n), fill(gstart.begin(), gstart.end() - 1);
-        for (int64_t i = 0; i < n; ++i) members[fill[pr[(size_t)i].group]++] = (uint32_t)i;
-        std::vector<uint32_t> order((size_t)G); std::iota(order.begin(), order.end(), 0u);
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-          const uint32_t sx = gstart[x + 1] - gstart[x], sy = gstart[y + 1] - gstart[y]; return sx != sy ? sx > sy : x < y; });
-        std::vector<uint8_t> used((size_t)N, 0), pilots((size_t)G, 0);
-        std::vector<uint32_t> slots;
-        bool ok = true;
-        for (uint32_t g : order) {
-          const uint32_t b = gstart[g], e = gstart[g + 1];
-          if (b == e) continue;
-          bool placed = false;
-          for (uint32_t pilot = 0; pilot < 256 && !placed; ++pilot) {
-            slots.clear(); bool clash = false;
-            for (uint32_t t = b; t < e && !clash; ++t) {
-              const uint32_t sl = ph_slot(pr[members[t]], pilot, h);
-              if (used[sl]) clash = true;
-              for (uint32_t x : slots) if (x == sl) clash = true;
-              slots.push_back(sl);
-            }
-            if (clash) continue;
-            for (uint32_t x : slots) used[x] = 1;
-            pilots[g] = (uint8_t)pilot; placed = true;
+  } else {
+  uint64_t nb64 = (uint64_t)((double)n_canon / (SLOTS_PER_BUCKET * TABLE_MAX_LOAD)) + 1;
+  if (nb64 < 256) nb64 = 256;
+  if (nb64 > 0x7FFFFFFFull) { delete ix; set_error("nb_index_build: k-mer table would exceed 2^31 buckets"); return NB_ERR_UNSUPPORTED; }
+  ix->hash.mf = 0x9E3779B1u; ix->hash.m1 = 0x85EBCA77u; ix->hash.n_buckets = (uint32_t)nb64;
+  Bucket empty; for (int j = 0; j < SLOTS_PER_BUCKET; ++j) { empty.slot[j].key = KEY_EMPTY; empty.slot[j].pay[0] = empty.slot[j].pay[1] = PAY_ABSENT; }
+  ix->buckets.assign((size_t)nb64, empty);
+  for (const Canon& c : canons) {
+    uint32_t b = kmer_bucket(c.key, ix->hash);
+    for (;;) {
+      Bucket& bk = ix->buckets[b];
+      int j = 0; while (j < SLOTS_PER_BUCKET && (bk.slot[j].key & KEY_MASK) != KEY_EMPTY) ++j;
+      if (j < SLOTS_PER_BUCKET) { bk.slot[j].key = (bk.slot[j].key & KEY_OVERFLOW) | c.key; bk.slot[j].pay[0] = c.pay[0]; bk.slot[j].pay[1] = c.pay[1]; break; }
+      bk.slot[0].key |= KEY_OVERFLOW;                         // full: lookups of keys homed at or before b continue
+      b = (b + 1 == ix->hash.n_buckets) ? 0 : b + 1;
+    }
+  }
+  }
+
+  // 5b. perfect-hash table (nb_internal.h): hash and displace, one-byte pilots, groups keyed by rem. Two sizes of first level:
+  //     small enough for LDS (<= PH_MAX_PILOT_BYTES: the lane-per-read kernels and the anchor kernel stage it per workgroup), or one pilot
+  //     per ~3 k-mers in global memory for the libraries whose table is far beyond the L2s anyway (anchor kernel only: one more L2-resident
+  //     load per lookup, but ~25 lookups per read instead of one per position).
+  const char* ph_env = std::getenv("NB_PH");
+  const bool dbg = std::getenv("NB_INDEX_DEBUG") != nullptr;
+  if (dbg) std::fprintf(stderr, "[nb_index] k=%d max_comp_words=%d max_desc_nw=%d n_canon=%lld\n", k, ix->max_comp_words, ix->max_desc_nw, (long long)n_canon);
+  if (k <= COMPACT_MAX_K && !(ph_env && ph_env[0] == '0')) {
+    static const uint32_t PMULS[2] = {0x9E3779B1u, 0x85EBCA77u};
+    const uint32_t hb = 2 * k > 32 ? (uint32_t)(2 * k - 32) : 0u;
+    const uint64_t nb_min = std::max<uint64_t>(256, 1ull << (hb + 2));
+    const uint32_t mul_a = ix->compact ? ix->chash.a : PMULS[0], mul_c = ix->compact ? ix->chash.c : PMULS[1];
+    const uint32_t himask = hb ? ((1u << hb) - 1u) : 0u;
+    const int64_t n = n_canon;
+    int64_t pilot_cap = PH_MAX_PILOT_BYTES;
+    if (const char* e = std::getenv("NB_PH_PILOT_KB")) { const int64_t v = std::atoll(e); if (v >= 1 && v <= 150) pilot_cap = v << 10; }
+    // groups: as many as the LDS budget of the first level allows, but not more than one per 2.5 k-mers (smaller groups fill the
+    // table higher: a group of s k-mers finds a free pilot among 256 only while (1 - fill)^s stays above a few per cent)
+    int64_t G = std::max<int64_t>(1, std::min<int64_t>(pilot_cap, (int64_t)((double)n / 2.5)));
+    int64_t table_cap = PH_MAX_TABLE_BYTES;
+    if ((double)n / (double)G > 16.0 || ix->max_desc_nw != 1) {         // too many k-mers for an LDS first level (or classes the lane kernel cannot hold):
+      G = std::max<int64_t>(1, (int64_t)((double)n / 3.0));              // first level in global memory, one pilot per 3 k-mers
+      table_cap = PH_LARGE_MAX_TABLE_BYTES;
+    }
+    const double lambda = (double)n / (double)G;
+    // (groups of ~3 k-mers with one-byte pilots fill to ~0.84: start there instead of walking down from 0.95, every failed attempt is a
+    //  full pass over the k-mers)
+    for (double alpha = table_cap == PH_MAX_TABLE_BYTES ? 0.95 : 0.86; alpha >= 0.55 && !ix->has_ph; alpha -= 0.02) {
+      const uint64_t N = std::max<uint64_t>({(uint64_t)((double)n / alpha) + 1, nb_min, 1024});
+      if (dbg) std::fprintf(stderr, "[nb_index] perfect hash: alpha=%.2f N=%llu G=%lld lambda=%.2f\n", alpha, (unsigned long long)N, (long long)G, lambda);
+      if ((int64_t)N * 16 > table_cap || N > 0x7FFFFFFFull || lambda > 16.0) break;
+      PHash h{}; h.a = mul_a; h.c = mul_c; h.n_slots = (uint32_t)N; h.n_groups = (uint32_t)G; h.hb = hb; h.himask = himask; h.stride = (uint32_t)(N >> (hb + 2));
+      if (h.stride >= (1u << 24) || hb + 2 > 16) break;                       // (24-bit multiply operands in ph_probe)
+      std::vector<PHProbe> pr((size_t)n);
+      std::vector<uint32_t> gcount((size_t)G + 1, 0);
+      for (int64_t i = 0; i < n; ++i) { pr[(size_t)i] = ph_probe(canons[(size_t)i].key, h); ++gcount[pr[(size_t)i].group + 1]; }
+      std::vector<uint32_t> gstart(gcount);
+      for (int64_t g = 0; g < G; ++g) gstart[(size_t)g + 1] += gstart[(size_t)g];
+      std::vector<uint32_t> members((size_t)n), fill(gstart.begin(), gstart.end() - 1);
+      for (int64_t i = 0; i < n; ++i) members[fill[pr[(size_t)i].group]++] = (uint32_t)i;
+      std::vector<uint32_t> order((size_t)G); std::iota(order.begin(), order.end(), 0u);
+      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const uint32_t sx = gstart[x + 1] - gstart[x], sy = gstart[y + 1] - gstart[y]; return sx != sy ? sx > sy : x < y; });
+      std::vector<uint8_t> used((size_t)N, 0), pilots((size_t)G, 0);
+      std::vector<uint32_t> slots;
+      bool ok = true;
+      for (uint32_t g : order) {
+        const uint32_t b = gstart[g], e = gstart[g + 1];
+        if (b == e) continue;
+        bool placed = false;
+        for (uint32_t pilot = 0; pilot < 256 && !placed; ++pilot) {
+          slots.clear(); bool clash = false;
+          for (uint32_t t = b; t < e && !clash; ++t) {
+            const uint32_t sl = ph_slot(pr[members[t]], pilot, h);
+            if (used[sl]) clash = true;
+            for (uint32_t x : slots) if (x == sl) clash = true;
+            slots.push_back(sl);
           }
-          if (!placed) { ok = false; break; }
+          if (clash) continue;
+          for (uint32_t x : slots) used[x] = 1;
+          pilots[g] = (uint8_t)pilot; placed = true;
         }
-        if (!ok) continue;
-        std::vector<PHEntry> tab((size_t)N, PHEntry{0xFFFFFFFFu, PAY_ABSENT, 0ull});
-        bool bad_key = false;
-        for (int64_t i = 0; i < n; ++i) {
-          const Canon& cn = canons[(size_t)i]; const PHProbe& q = pr[(size_t)i];
-          const bool both = cn.pay[0] != PAY_ABSENT && cn.pay[1] != PAY_ABSENT;
-          const int strand = cn.pay[0] != PAY_ABSENT ? 0 : 1;
-          const uint32_t pay = cn.pay[strand], colour = pay >> 10;
-          const ColDesc& d = ix->desc[colour];
-          PHEntry en; en.key = q.want | (both ? 2u : 0u) | (uint32_t)strand;
-          en.pay = (pay & 0x3FFu) | (d.nw == 1 ? (d.w0 << 11) : ((1u << 10) | (colour << 11)));
-          en.m = d.nw == 1 ? d.m0 : 0ull;
-          if (en.key == 0xFFFFFFFFu || d.w0 > 0x1FFFFFu || colour > 0x1FFFFFu) bad_key = true;
-          tab[ph_slot(q, pilots[q.group], h)] = en;
-        }
-        if (bad_key) break;
-        ix->has_ph = true; ix->ph = h; ix->ph_table.swap(tab); ix->ph_pilots.swap(pilots);
+        if (!placed) { ok = false; if (dbg) std::fprintf(stderr, "[nb_index]   a group of %u k-mers found no pilot\n", e - b); break; }
       }
+      if (!ok) continue;
+      std::vector<PHEntry> tab((size_t)N, PHEntry{0xFFFFFFFFu, PAY_ABSENT, 0ull});
+      bool bad_key = false;
+      for (int64_t i = 0; i < n; ++i) {
+        const Canon& cn = canons[(size_t)i]; const PHProbe& q = pr[(size_t)i];
+        const bool both = cn.pay[0] != PAY_ABSENT && cn.pay[1] != PAY_ABSENT;
+        const int strand = cn.pay[0] != PAY_ABSENT ? 0 : 1;
+        const uint32_t pay = cn.pay[strand], colour = pay >> 10;
+        const ColDesc& d = ix->desc[colour];
+        PHEntry en; en.key = q.want | (both ? 2u : 0u) | (uint32_t)strand;
+        en.pay = (pay & 0x3FFu) | (d.nw == 1 ? (d.w0 << 11) : ((1u << 10) | (colour << 11)));
+        en.m = d.nw == 1 ? d.m0 : 0ull;
+        if (en.key == 0xFFFFFFFFu || d.w0 > 0x1FFFFFu || colour > 0x1FFFFFu) bad_key = true;
+        tab[ph_slot(q, pilots[q.group], h)] = en;
+      }
+      if (bad_key) { if (dbg) std::fprintf(stderr, "[nb_index]   key / word index out of range\n"); break; }
+      ix->has_ph = true; ix->ph = h; ix->ph_table.swap(tab); ix->ph_pilots.swap(pilots);
     }
 
     // 5c. anchor structures of the anchor-extend kernel (nb_internal.h): text, per-k-mer anchor (first occurrence) + room, sparse AND table
     const char* an_env = std::getenv("NB_ANCHOR");
     int64_t T = 0;
     for (int s = 0; s < n_seqs; ++s) T += lens[s];
-    if (ix->has_ph && !(an_env && an_env[0] == '0') && T < ANCHOR_MAX_TEXT) {
+    // words per sparse-table entry: the widest component, two at the most. Sequences of wider components (loci merged by shared k-mers,
+    // repeat families) keep their anchors but are marked: a read that meets one is mapped by the wave-per-read kernel. No anchors at all
+    // when that would be more than a quarter of the library.
+    const int NW = std::min(ix->max_comp_words, 2);
+    int64_t wide_bases = 0;
+    for (int s = 0; s < n_seqs; ++s) if ((int)ix->comp_nw[(size_t)s] > NW) wide_bases += lens[s];
+    if (ix->has_ph && !(an_env && an_env[0] == '0') && T < ANCHOR_MAX_TEXT && (int64_t)ANCHOR_LEVELS * T * NW * 8 <= ANCHOR_MAX_SPARSE_BYTES && wide_bases * 4 <= T) {
       std::vector<uint8_t> code((size_t)T);
       std::vector<uint32_t> vrun((size_t)T + 1, 0);          // valid bases from j to the end of its sequence / the next N
+      std::vector<uint32_t> seq_at((size_t)T);
       { int64_t j0 = 0;
         for (int s = 0; s < n_seqs; ++s) {
-          for (int64_t i = 0; i < lens[s]; ++i) code[(size_t)(j0 + i)] = (uint8_t)code_of(seqs[s][i]);
+          for (int64_t i = 0; i < lens[s]; ++i) { code[(size_t)(j0 + i)] = (uint8_t)code_of(seqs[s][i]); seq_at[(size_t)(j0 + i)] = (uint32_t)s; }
           uint32_t run = 0;
           for (int64_t i = lens[s] - 1; i >= 0; --i) { run = code[(size_t)(j0 + i)] == 4 ? 0u : run + 1u; vrun[(size_t)(j0 + i)] = run; }
           j0 += lens[s];
         } }
-      ix->text_len = T;
+      ix->text_len = T; ix->anchor_nw = NW;
       ix->text.assign((size_t)((T + 15) / 16 + 4), 0u);
       for (int64_t j = 0; j < T; ++j) if (code[(size_t)j] < 4) ix->text[(size_t)(j >> 4)] |= (uint32_t)code[(size_t)j] << (2 * (j & 15));
-      // canonical entry (index into canons) and strand flag of the k-mer that starts at every text position
+      // canonical entry (index into canons) of the k-mer that starts at every text position
       constexpr uint32_t NONE = 0xFFFFFFFFu;
       std::vector<uint32_t> cidx((size_t)T, NONE);
       parallel_ranges((size_t)T, threads, [&](size_t lo, size_t hi) {
@@ -407,48 +456,45 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         const uint32_t a = cidx[(size_t)j], b = cidx[(size_t)j + 1];
         room[(size_t)j] = (a != NONE && b != NONE && !is_both(b)) ? (uint8_t)std::min<uint32_t>((uint32_t)room[(size_t)j + 1] + 1u, ANCHOR_MAX_ROOM) : (uint8_t)0;
       }
-      ix->sparse.assign((size_t)ANCHOR_LEVELS * (size_t)T, 0ull);
-      for (int64_t j = 0; j < T; ++j) {
-        const uint32_t i = cidx[(size_t)j];
-        if (i == NONE) continue;
-        const Canon& cn = canons[i];
-        const uint32_t pay = cn.pay[0] != PAY_ABSENT ? cn.pay[0] : cn.pay[1];      // (both strands: never part of a run, any class will do)
-        ix->sparse[(size_t)j] = ix->desc[pay >> 10].m0;
-      }
+      // level 0: the class of the k-mer at every text position as NW words from the first word of its sequence's component
+      ix->sparse.assign((size_t)ANCHOR_LEVELS * (size_t)T * (size_t)NW, 0ull);
+      parallel_ranges((size_t)T, threads, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+          const uint32_t i = cidx[j];
+          if (i == NONE) continue;
+          const Canon& cn = canons[i];
+          const uint32_t pay = cn.pay[0] != PAY_ABSENT ? cn.pay[0] : cn.pay[1];      // (both strands: never part of a run, any class will do)
+          const ColDesc& d = ix->desc[pay >> 10];
+          if ((int)ix->comp_nw[seq_at[j]] > NW) continue;      // (marked in the anchor entry: never read)
+          const uint32_t base = ix->comp_w0[seq_at[j]];
+          uint64_t* e = ix->sparse.data() + j * (size_t)NW;
+          if (d.w0 >= base && d.w0 - base < (uint32_t)NW) e[d.w0 - base] = d.m0;
+          if (d.nw > 1 && d.w0 + 1 >= base && d.w0 + 1 - base < (uint32_t)NW) e[d.w0 + 1 - base] = d.m1;
+        }
+      });
       for (int l = 1; l < ANCHOR_LEVELS; ++l) {
-        const uint64_t* prev = ix->sparse.data() + (size_t)(l - 1) * (size_t)T; uint64_t* cur = ix->sparse.data() + (size_t)l * (size_t)T;
+        const uint64_t* prev = ix->sparse.data() + (size_t)(l - 1) * (size_t)T * (size_t)NW; uint64_t* cur = ix->sparse.data() + (size_t)l * (size_t)T * (size_t)NW;
         const int64_t half = 1ll << (l - 1);
         parallel_ranges((size_t)T, threads, [&](size_t lo, size_t hi) {
-          for (size_t j = lo; j < hi; ++j) cur[j] = ((int64_t)j + half < T) ? (prev[j] & prev[j + (size_t)half]) : 0ull;
+          for (size_t j = lo; j < hi; ++j) for (int w = 0; w < NW; ++w)
+            cur[j * (size_t)NW + (size_t)w] = ((int64_t)j + half < T) ? (prev[j * (size_t)NW + (size_t)w] & prev[(j + (size_t)half) * (size_t)NW + (size_t)w]) : 0ull;
         });
       }
       ix->atable.assign(ix->ph_table.size(), AEntry{0xFFFFFFFFu, PAY_ABSENT, 0u, 0u});
+      bool fits = true;
       for (int64_t i = 0; i < n_canon; ++i) {
         const PHProbe q = ph_probe(canons[(size_t)i].key, ix->ph);
         const uint32_t slot = ph_slot(q, ix->ph_pilots[q.group], ix->ph);
         const PHEntry& pe = ix->ph_table[slot];
         const uint32_t t = tpos_of[(size_t)i];
-        ix->atable[slot] = AEntry{pe.key, pe.pay, t == NONE ? 0u : t, (t == NONE || is_both((uint32_t)i)) ? 0u : (uint32_t)room[t]};
+        const uint32_t base = t == NONE ? 0u : ix->comp_w0[seq_at[t]];
+        if (base > 0xFFFFu) fits = false;
+        const uint32_t wide = (t != NONE && (int)ix->comp_nw[seq_at[t]] > NW) ? ANCHOR_WIDE : 0u;
+        ix->atable[slot] = AEntry{pe.key, pe.pay, t == NONE ? 0u : t, ((t == NONE || is_both((uint32_t)i)) ? 0u : (uint32_t)room[t]) | wide | (base << 16)};
       }
-      ix->has_anchor = true;
+      ix->has_anchor = fits;
+      if (!fits) { std::vector<AEntry>().swap(ix->atable); std::vector<uint64_t>().swap(ix->sparse); std::vector<uint32_t>().swap(ix->text); }
     }
-  } else {
-  uint64_t nb64 = (uint64_t)((double)n_canon / (SLOTS_PER_BUCKET * TABLE_MAX_LOAD)) + 1;
-  if (nb64 < 256) nb64 = 256;
-  if (nb64 > 0x7FFFFFFFull) { delete ix; set_error("nb_index_build: k-mer table would exceed 2^31 buckets"); return NB_ERR_UNSUPPORTED; }
-  ix->hash.mf = 0x9E3779B1u; ix->hash.m1 = 0x85EBCA77u; ix->hash.n_buckets = (uint32_t)nb64;
-  Bucket empty; for (int j = 0; j < SLOTS_PER_BUCKET; ++j) { empty.slot[j].key = KEY_EMPTY; empty.slot[j].pay[0] = empty.slot[j].pay[1] = PAY_ABSENT; }
-  ix->buckets.assign((size_t)nb64, empty);
-  for (const Canon& c : canons) {
-    uint32_t b = kmer_bucket(c.key, ix->hash);
-    for (;;) {
-      Bucket& bk = ix->buckets[b];
-      int j = 0; while (j < SLOTS_PER_BUCKET && (bk.slot[j].key & KEY_MASK) != KEY_EMPTY) ++j;
-      if (j < SLOTS_PER_BUCKET) { bk.slot[j].key = (bk.slot[j].key & KEY_OVERFLOW) | c.key; bk.slot[j].pay[0] = c.pay[0]; bk.slot[j].pay[1] = c.pay[1]; break; }
-      bk.slot[0].key |= KEY_OVERFLOW;                         // full: lookups of keys homed at or before b continue
-      b = (b + 1 == ix->hash.n_buckets) ? 0 : b + 1;
-    }
-  }
   }
   ix->n_canonical = n_canon;
   *out = ix;

@@ -154,15 +154,22 @@ NB_HD inline uint32_t ph_slot(const PHProbe& p, uint32_t pilot, const PHash& h) 
 //   text      the library sequences concatenated, 2 bits per base, 16 bases per u32 (base j at bits [2(j & 15), +2) of word j >> 4);
 //             N is stored as A and never compared: `room` stops a run before it
 //   AEntry    same slot, key and pay as the PHEntry of the k-mer (same PHash, same pilots); tpos = text position of the anchor
-//             occurrence; room = how many times the walk may step to the NEXT text k-mer from there: the following k-mers are valid
-//             (no N, same sequence), do not occur on both strands, and the run stays below 2^ANCHOR_LEVELS positions
-//   sparse    level l, position t: AND of the class words (internal numbering, one word: only built when max_desc_nw == 1; all k-mers of
-//             a sequence lie in the word of the sequence's component) of the k-mers at text positions [t, t + 2^l); level-major
+//             occurrence; room (low 16 bits) = how many times the walk may step to the NEXT text k-mer from there: the following k-mers
+//             are valid (no N, same sequence), do not occur on both strands, and the run stays below 2^ANCHOR_LEVELS positions; bit 15 =
+//             the component of the anchor sequence spans more class-row words than a sparse-table entry holds (the read is then mapped
+//             by the wave-per-read kernel); the high 16 bits = first class-row word of that component
+//   sparse    level l, position t: AND of the classes of the k-mers at text positions [t, t + 2^l), as NW = anchor_nw words (1 or 2)
+//             counted from the first word of the sequence's component (internal numbering: every class of a k-mer of a sequence lies
+//             inside that component's words, so the AND is plain word arithmetic); level-major, then position, then word
 struct AEntry { uint32_t key, pay, tpos, room; };
 static_assert(sizeof(AEntry) == 16, "anchor entry must be 16 bytes");
 constexpr int ANCHOR_LEVELS = 8;                        // runs of up to 255 k-mer positions
 constexpr uint32_t ANCHOR_MAX_ROOM = (1u << ANCHOR_LEVELS) - 2;
+constexpr uint32_t ANCHOR_ROOM_MASK = 0x7FFFu;          // AEntry.room: bits [0,15) room, bit 15 ANCHOR_WIDE, bits [16,32) first class-row word of the component
+constexpr uint32_t ANCHOR_WIDE = 1u << 15;              // the anchor sequence's component is wider than the sparse table's entries
 constexpr int64_t ANCHOR_MAX_TEXT = 1ll << 31;
+constexpr int64_t ANCHOR_MAX_SPARSE_BYTES = 8ll << 30;  // 8 levels x 8 (16) bytes per library base: libraries up to ~130 (65) M bases
+constexpr int64_t PH_LARGE_MAX_TABLE_BYTES = 4ll << 30; // perfect-hash table with its first level in global memory
 
 // A colour (equivalence class of the graph) for the wave-per-read kernels: the span of u64 words of its bitset that can be non-zero, with
 // the first two words inline (32 bytes, two dwordx4 issued together). Bit positions are INTERNAL sequence numbers: the index builder
@@ -209,6 +216,10 @@ struct HostIndex {
   std::vector<PHEntry> ph_table;      // ph.n_slots entries
   std::vector<uint8_t> ph_pilots;     // ph.n_groups bytes
   bool has_anchor = false;            // anchor structures of nb_anchor.hip (built next to the perfect-hash table)
+  int anchor_nw = 1;                  // words per sparse-table entry
+  int max_comp_words = 1;             // class-row words of the widest connected component (internal numbering)
+  std::vector<uint32_t> comp_w0;      // per sequence: first class-row word of its component
+  std::vector<uint32_t> comp_nw;      // per sequence: class-row words its component spans
   int64_t text_len = 0;               // bases in `text`
   std::vector<uint32_t> text;         // text_len bases + 64 bases of padding
   std::vector<AEntry> atable;         // ph.n_slots entries, slot for slot the k-mers of ph_table

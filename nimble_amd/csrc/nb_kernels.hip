@@ -1234,16 +1234,20 @@ int32_t nb_index_anchor_query(const nb_index* ix, const char* kmer, int32_t run,
   const AEntry& e = h.atable[ph_slot(q, h.ph_pilots[q.group], h.ph)];
   const uint32_t d = e.key ^ q.want;
   if (d >= 4u || (d & 2u) || (d & 1u) != o) return 0;
+  const uint32_t rm = e.room & ANCHOR_ROOM_MASK, w0 = e.room >> 16;
   if (tpos) *tpos = (int64_t)e.tpos;
-  if (room) *room = (int32_t)e.room;
+  if (room) *room = (int32_t)rm;
+  if (e.room & ANCHOR_WIDE) return 2;
   if (colour_and) {
-    const uint32_t n = (uint32_t)std::min<int64_t>(run, (int64_t)e.room) + 1u;
+    const uint32_t n = (uint32_t)std::min<int64_t>(run, (int64_t)rm) + 1u;
     int lv = 0; while ((2u << lv) <= n) ++lv;
-    const uint64_t* sp = h.sparse.data() + (size_t)lv * (size_t)h.text_len + e.tpos;
-    const uint64_t v = sp[0] & sp[n - (1u << lv)];
-    const uint32_t w0 = e.pay >> 11;
+    const size_t NW = (size_t)h.anchor_nw;
+    const uint64_t* sp = h.sparse.data() + ((size_t)lv * (size_t)h.text_len + e.tpos) * NW;
     std::memset(colour_and, 0, (size_t)h.words * 8);
-    for (int b = 0; b < 64; ++b) if ((v >> b) & 1ull) { const int32_t orig = h.inv_perm[(size_t)w0 * 64 + (size_t)b]; if (orig >= 0) colour_and[orig >> 6] |= 1ull << (orig & 63); }
+    for (size_t w = 0; w < NW; ++w) {
+      const uint64_t v = sp[w] & sp[(size_t)(n - (1u << lv)) * NW + w];
+      for (int b = 0; b < 64; ++b) if ((v >> b) & 1ull) { const int32_t orig = h.inv_perm[((size_t)w0 + w) * 64 + (size_t)b]; if (orig >= 0) colour_and[orig >> 6] |= 1ull << (orig & 63); }
+    }
   }
   return 1;
 }
@@ -1262,7 +1266,7 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
     NB_HIP(hipMemcpy(c->d_ph_pilots, h.ph_pilots.data(), h.ph_pilots.size(), hipMemcpyHostToDevice));
   }
   (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr;
-  c->has_anchor = h.has_anchor; c->text_len = h.text_len;
+  c->has_anchor = h.has_anchor; c->text_len = h.text_len; c->anchor_nw = h.anchor_nw;
   if (h.has_anchor) {
     NB_HIP(hipMalloc((void**)&c->d_atable, h.atable.size() * sizeof(AEntry))); NB_HIP(hipMalloc((void**)&c->d_text, h.text.size() * 4)); NB_HIP(hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8));
     NB_HIP(hipMemcpy(c->d_atable, h.atable.data(), h.atable.size() * sizeof(AEntry), hipMemcpyHostToDevice));
@@ -1341,8 +1345,13 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   // batch (forward orientation, then the reads whose better strand is the reverse one); what the online walk cannot finish exactly is
   // gathered and goes through the wave-per-read kernel below.
   const char* lane_env = std::getenv("NB_LANE");
+  const char* anchor_env = std::getenv("NB_ANCHOR");
   int lane_wpb = 0;
-  if (!d_mates && cfg->num_mismatches == 0 && c->has_ph && positions >= 1 && n < (1ll << 31) && !(lane_env && lane_env[0] == '0') && lane_lds_bytes(c, max_len, &lane_wpb) > 0) {
+  // anchor-extend kernel (nb_anchor.hip) when the index carries the anchor structures: far fewer lookups per read; else the lane-per-read
+  // kernels of nb_lane.hip (first level of the table must fit LDS)
+  const bool use_anchor = c->has_anchor && !(anchor_env && anchor_env[0] == '0') && anchor_fits(c, max_len);
+  if (!d_mates && cfg->num_mismatches == 0 && c->has_ph && positions >= 1 && n < (1ll << 31) && !(lane_env && lane_env[0] == '0') &&
+      (use_anchor || lane_lds_bytes(c, max_len, &lane_wpb) > 0)) {
     const int64_t stride = a.stride;
     if (c->lists_cap < n) {
       (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;
@@ -1355,9 +1364,6 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     }
     if (!c->d_list_counters) NB_HIP(hipMalloc((void**)&c->d_list_counters, 8));
     LaneLists ll{c->d_lists, c->d_lists + c->lists_cap, c->d_list_counters};
-    // anchor-extend kernel (nb_anchor.hip) when the index carries the anchor structures: one launch, far fewer lookups per read
-    const char* anchor_env = std::getenv("NB_ANCHOR");
-    const bool use_anchor = c->has_anchor && !(anchor_env && anchor_env[0] == '0');
     rc = use_anchor ? launch_anchor(c, nr, ix, a, ll, s) : launch_lane(c, nr, ix, a, ll, s); if (rc != NB_OK) return rc;
     { char buf[96];
       if (use_anchor) std::snprintf(buf, sizeof buf, "nb_anchor_kernel<%d>;nb_anchor_scan_kernel<%d>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr);
@@ -1368,7 +1374,8 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     b.reads = c->d_redo_reads; b.lens = a.lens ? c->d_redo_lens : nullptr; b.n_dev = c->d_list_counters + 1;
     b.out_class = a.out_class ? c->d_redo_out : nullptr; b.out_info = a.out_info ? c->d_redo_out + c->lists_cap : nullptr;
     b.out_cov = a.out_cov ? reinterpret_cast<uint64_t*>(c->d_redo_out + 2 * c->lists_cap) : nullptr;
-    rc = (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, b, s) : dispatch_se<4, true>(c, nr, positions, ix, b, s);
+    if (c->compact) rc = (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, b, s) : dispatch_se<4, true>(c, nr, positions, ix, b, s);
+    else rc = (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, b, s) : dispatch_se<4, false>(c, nr, positions, ix, b, s);   // (anchors next to the wide table)
     if (rc != NB_OK) return rc;
     BatchArgs sc = a; sc.n = c->lists_cap;
     return launch_lane_scatter(c, sc, ll, c->d_redo_out, s);

@@ -99,7 +99,7 @@ class Index:
                                                     bits.ctypes.data_as(_lib.c_u64p)))
         if rc == 0:
             return None
-        return {"tpos": tpos.value, "room": room.value, "members": bits_to_members(bits)}
+        return {"tpos": tpos.value, "room": room.value, "members": bits_to_members(bits) if rc == 1 else None}
 
     def close(self):
         if getattr(self, "_h", None):

@@ -129,3 +129,39 @@ def test_both_strand_kmers_next_to_runs(built):
         r = strs[a][o:o + L]
         reads.append(r if rng.random() < 0.5 else rc(r))
     _check(strs, 20, reads, 150, "both strands next to runs")
+
+
+@pytest.mark.parametrize("table", ["default", "wide"])
+def test_two_word_classes_and_global_first_level(built, table, monkeypatch):
+    """Loci of 90 alleles: classes span two words (sparse table with 16-byte entries, two-word interning), the first level of the
+    perfect-hash table is sized for global memory; once next to the compact table, once next to the wide table (the BASELINE configs[4]
+    shape: 100-allele loci, table beyond the L2s)."""
+    if table == "wide":
+        monkeypatch.setenv("NB_TABLE", "wide")
+    _, seqs, strs, _ = library_strings(3, 90, locus_len=260, seed=61)
+    rng = np.random.default_rng(2)
+    codes = synth.synth_reads(seqs, 6000, 150, seed=12, err=0.012, n_rate=0.002)
+    reads = ["".join("ACGTN"[c] for c in row) for row in codes]
+    for j in range(0, 600, 7):                                 # ragged lengths too
+        reads[j] = reads[j][:int(rng.integers(15, 150))]
+    ora = _check(strs, 20, reads, 150, f"two-word classes ({table} table)")
+    assert (ora["reason"] == 0).mean() > 0.4
+    both_words = 0                                             # result sets with members in BOTH class-row words of their locus (alleles 0-63 | 64-89)
+    for row in ora["set_bits"][ora["reason"] == 0]:
+        within = np.array(engine.bits_to_members(row)) % 90
+        both_words += bool((within < 64).any() and (within >= 64).any())
+    assert both_words > 100
+    _check(strs, 20, reads[:1500], 150, "two-word classes, discard multiple", cfg=engine.make_config(discard_multiple_matches=True))
+
+
+def test_component_wider_than_the_sparse_entries(built):
+    """Two 70-allele loci that share a block form one component of three class-row words: their anchors are marked, reads that touch them
+    are mapped by the wave-per-read kernel, reads of the other loci by the anchor kernel — in one batch."""
+    _, seqs, strs, _ = library_strings(9, 70, locus_len=120, seed=17)
+    strs[5] = strs[5][:40] + strs[80][30:60] + strs[5][70:]
+    lut = np.zeros(256, dtype=np.uint8); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
+    codes = synth.synth_reads([lut[np.frombuffer(s.encode(), dtype=np.uint8)] for s in strs], 5000, 100, seed=3, err=0.01)
+    reads = ["".join("ACGTN"[c] for c in row) for row in codes]
+    reads += [strs[5][10:110], rc(strs[5][5:105]), strs[80][0:100]]
+    ora = _check(strs, 20, reads, 100, "wide component")
+    assert (ora["reason"] == 0).mean() > 0.4

@@ -88,21 +88,31 @@ def test_index_with_reverse_complement_sequences(built):
         assert ix.query(p) == ox.query(p), p
 
 
-@pytest.mark.parametrize("with_rc", [False, True])
-def test_anchor_structures(built, with_rc):
+@pytest.mark.parametrize("with_rc,alleles,wide_table,merged", [(False, 6, False, False), (True, 6, False, False), (False, 70, False, False),
+                                                               (False, 6, True, False), (False, 70, False, True)])
+def test_anchor_structures(built, with_rc, alleles, wide_table, merged, monkeypatch):
     """Anchor structures of the anchor-extend kernel (csrc/nb_internal.h, AEntry): for library k-mers and their neighbours
       * the anchor is an occurrence (the first one) of the k-mer in the concatenated library text,
       * room = how far the text can be followed from there: next k-mers valid (no N, same sequence), not present on both strands, < 255,
       * the sparse-table AND over [tpos, tpos + run] equals the AND of the classes nb_index_query reports for those text k-mers,
-    and k-mers that are absent, or present on both strands, have no anchor."""
-    _, _, strs, _ = library_strings(3, 6, locus_len=420, seed=17)
+    and k-mers that are absent, or present on both strands, have no anchor. Also with loci of 70 alleles (classes of two words, first level of
+    the table sized for global memory), next to the wide k-mer table, and with two 70-allele loci merged into one component of three
+    words by a shared block (anchors in it are marked: no class words, the wave-per-read kernel maps such reads)."""
+    if wide_table:
+        monkeypatch.setenv("NB_TABLE", "wide")
+    _, _, strs, _ = library_strings(9 if merged else 3, alleles, locus_len=420 if alleles < 20 else (100 if merged else 150), seed=17)
+    if merged:
+        strs[5] = strs[5][:40] + strs[80][30:60] + strs[5][70:]
     strs[2] = strs[2][:100] + "N" + strs[2][101:]
     comp = str.maketrans("ACGTN", "TGCAN")
     if with_rc:
         strs = strs + [strs[4].translate(comp)[::-1], strs[7][:200]]
     K = 20
     ix = engine.Index(strs, K)
-    assert ix.stats()["anchor_bytes"] > 0
+    st = ix.stats()
+    assert st["anchor_bytes"] > 0 and st["compact"] == (0 if wide_table else 1)
+    if alleles > 64:
+        assert st["words_internal"] == (17 if merged else 6) and st["ph_pilot_bytes"] > st["n_canonical"] / 3.5      # two words per locus; one pilot per ~3 k-mers
     text = "".join(s.upper() for s in strs)
     starts = np.cumsum([0] + [len(s) for s in strs])
     seq_of = np.repeat(np.arange(len(strs)), [len(s) for s in strs])
@@ -117,13 +127,17 @@ def test_anchor_structures(built, with_rc):
             first.setdefault(km, t)
             if km not in info:
                 info[km] = (ix.query(km), ix.query(km.translate(comp)[::-1]) is not None)
-    checked = both = 0
-    for km, t0 in list(first.items())[::3]:
+    checked = both = wide = 0
+    for km, t0 in list(first.items())[::3 if alleles < 20 else (23 if merged else 7)]:
         q, is_both = info[km]
         a = ix.anchor_query(km, 0)
         if is_both:
             assert a is None
             both += 1
+            continue
+        if merged and int(seq_of[t0]) < 140:                 # loci 0 and 1 are one component of 140 sequences = three words
+            assert a is not None and a["tpos"] == t0 and a["members"] is None
+            wide += 1
             continue
         assert a is not None and a["tpos"] == t0 and a["members"] == q["members"]
         room = 0
@@ -139,7 +153,7 @@ def test_anchor_structures(built, with_rc):
                 want &= set(info[kmer_at(t0 + i)][0]["members"])
             assert ix.anchor_query(km, run)["members"] == sorted(want), (km, run)
         checked += 1
-    assert checked > 800 and (both > 100) == with_rc
+    assert checked > (300 if merged else 600) and (both > 100) == with_rc and (wide > 50) == merged
     rng = np.random.default_rng(3)
     for _ in range(2000):
         assert ix.anchor_query("".join("ACGT"[c] for c in rng.integers(0, 4, K))) is None
