@@ -542,6 +542,11 @@ bool anchor_fits(const nb_ctx* c, int max_len) {
   return c->has_anchor && anchor_lds_bytes(c, max_len, &w, &plds) > 0;
 }
 
+bool anchor_pilots_in_lds(const nb_ctx* c, int max_len) {
+  int w = 0; bool plds = false;
+  return anchor_lds_bytes(c, max_len, &w, &plds) > 0 && plds;
+}
+
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
   int waves = 0; bool plds = false;
   const int64_t lds = anchor_lds_bytes(c, a.max_len, &waves, &plds);

@@ -326,6 +326,7 @@ namespace nb {
 // nb_anchor.hip: the anchor-extend kernel (one launch; what it cannot finish exactly goes on ll.redo_list like the lane path's)
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
 bool anchor_fits(const nb_ctx* c, int max_len);
+bool anchor_pilots_in_lds(const nb_ctx* c, int max_len);   // which instantiation launch_anchor picks (kernel names for the profiles)
 // nb_lane.hip: both lane-per-read passes of one batch, then gather of the redo reads; nb_lane_scatter puts their results back
 int launch_lane(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
 int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block);   // 0 = the lane path does not fit this shape
