@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--loci", type=int, default=None)
     ap.add_argument("--alleles", type=int, default=None)
     ap.add_argument("--k", type=int, default=20)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="upper bound of the reads timed on the CPU baseline (rank 0, N=1 only); the "
+    ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="upper bound of the reads timed on the CPU baseline (rank 0, N=1 only); the "
                     "actual sample is sized from a calibration slice so that the timed call runs about --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="target wall time of the timed CPU-baseline call")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default min(host cores, 32))")

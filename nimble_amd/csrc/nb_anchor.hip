@@ -465,9 +465,10 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
     }
     bool hit = false;
     while (__ballot(any_set<NR>(todo))) {
-      Look kk[4]; bool vv[4];
+      constexpr int U = 8;
+      Look kk[U]; bool vv[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         int p = -1;
 #pragma unroll
         for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
         kk[u] = anchor_lookup<PLDS>(h, s_pilots, w & kmask, vv[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) hit = hit || (vv[u] && ((kk[u].e.x ^ kk[u].want) < 4u));
+      for (int u = 0; u < U; ++u) hit = hit || (vv[u] && ((kk[u].e.x ^ kk[u].want) < 4u));
       if (hit) {
 #pragma unroll
         for (int wi = 0; wi < NR; ++wi) todo.w[wi] = 0;

@@ -355,7 +355,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     const double lambda = (double)n / (double)G;
     // (groups of ~3 k-mers with one-byte pilots fill to ~0.84: start there instead of walking down from 0.95, every failed attempt is a
     //  full pass over the k-mers)
-    for (double alpha = table_cap == PH_MAX_TABLE_BYTES ? 0.95 : 0.86; alpha >= 0.55 && !ix->has_ph; alpha -= 0.02) {
+    for (double alpha = table_cap == PH_MAX_TABLE_BYTES ? 0.95 : 0.84; alpha >= 0.55 && !ix->has_ph; alpha -= 0.02) {
       const uint64_t N = std::max<uint64_t>({(uint64_t)((double)n / alpha) + 1, nb_min, 1024});
       if (dbg) std::fprintf(stderr, "[nb_index] perfect hash: alpha=%.2f N=%llu G=%lld lambda=%.2f\n", alpha, (unsigned long long)N, (long long)G, lambda);
       if ((int64_t)N * 16 > table_cap || N > 0x7FFFFFFFull || lambda > 16.0) break;

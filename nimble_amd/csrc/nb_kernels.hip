@@ -1268,10 +1268,19 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr;
   c->has_anchor = h.has_anchor; c->text_len = h.text_len; c->anchor_nw = h.anchor_nw;
   if (h.has_anchor) {
-    NB_HIP(hipMalloc((void**)&c->d_atable, h.atable.size() * sizeof(AEntry))); NB_HIP(hipMalloc((void**)&c->d_text, h.text.size() * 4)); NB_HIP(hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8));
-    NB_HIP(hipMemcpy(c->d_atable, h.atable.data(), h.atable.size() * sizeof(AEntry), hipMemcpyHostToDevice));
-    NB_HIP(hipMemcpy(c->d_text, h.text.data(), h.text.size() * 4, hipMemcpyHostToDevice));
-    NB_HIP(hipMemcpy(c->d_sparse, h.sparse.data(), h.sparse.size() * 8, hipMemcpyHostToDevice));
+    // (the sparse table is the one large piece — 8 or 16 bytes x 8 levels per library base: if it does not fit next to the caller's
+    //  buffers the index still works, through the kernels that do not need it)
+    const bool got = hipMalloc((void**)&c->d_atable, h.atable.size() * sizeof(AEntry)) == hipSuccess && hipMalloc((void**)&c->d_text, h.text.size() * 4) == hipSuccess &&
+                     hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8) == hipSuccess;
+    if (!got) {
+      (void)hipGetLastError();
+      (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr;
+      c->has_anchor = false;
+    } else {
+      NB_HIP(hipMemcpy(c->d_atable, h.atable.data(), h.atable.size() * sizeof(AEntry), hipMemcpyHostToDevice));
+      NB_HIP(hipMemcpy(c->d_text, h.text.data(), h.text.size() * 4, hipMemcpyHostToDevice));
+      NB_HIP(hipMemcpy(c->d_sparse, h.sparse.data(), h.sparse.size() * 8, hipMemcpyHostToDevice));
+    }
   }
   if (h.compact) {
     NB_HIP(hipMalloc((void**)&c->d_ctable, h.ctable.size() * sizeof(CBucket)));
