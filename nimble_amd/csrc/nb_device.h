@@ -350,6 +350,8 @@ struct nb_ctx {
   void* d_lane_tail = nullptr;     // LaneTail of the current batch (nb_lane.hip)
   nb::PHEntry* d_ph_table = nullptr; uint8_t* d_ph_pilots = nullptr; nb::PHash ph{}; bool has_ph = false;   // perfect-hash table of the lane kernels
   nb::AEntry* d_atable = nullptr; uint32_t* d_text = nullptr; uint64_t* d_sparse = nullptr; long long text_len = 0; bool has_anchor = false; int anchor_nw = 1;   // anchor structures (nb_anchor.hip)
+  hipStream_t copy_stream = nullptr; hipStream_t last_stream = nullptr; bool last_stream_set = false;   // read-back stream; stream of the last nb_align_batch
+  void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned host staging buffer of nb_classes_read (grown on demand, kept between calls)
   std::string last_kernels;        // kernels launched by the last nb_align_batch (nb_last_kernel_names)   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
   // score_percent table
   uint16_t* d_pct = nullptr; int pct_len = 0; double pct_value = -1.0; std::vector<uint16_t> pct_host;

@@ -18,6 +18,7 @@
 // Integer/bit work only: no MFMA. Wave = 64 everywhere.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -1138,6 +1139,11 @@ int32_t nb_ctx_create(int32_t device_id, int64_t max_classes, nb_ctx** out) {
   NB_HIP(hipMemset(c->ct.counts, 0, (size_t)max_classes * 8));
   NB_HIP(hipMemset(c->ct.n_classes, 0, 4)); NB_HIP(hipMemset(c->ct.err, 0, 4)); NB_HIP(hipMemset(c->ct.reasons, 0, NB_NUM_REASONS * 8));
   c->ct.rows = nullptr;  // sized at index upload (needs W)
+  // read-backs (class rows, counts, reasons) go through a pinned staging buffer and a stream of their own, both made here: the first
+  // pinned allocation / first pageable copy of a process costs tens of milliseconds, which must not land in a caller's timed region
+  NB_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  c->h_stage_cap = (size_t)32 << 20;
+  NB_HIP(hipHostMalloc(&c->h_stage, c->h_stage_cap, hipHostMallocDefault));
   *out = c; return NB_OK;
 }
 
@@ -1145,7 +1151,8 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_lane_tail); (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_lane_tail); if (c->h_stage) (void)hipHostFree(c->h_stage); if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
 
@@ -1338,6 +1345,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   if (n == 0) return NB_OK;
   NB_HIP(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
+  c->last_stream = s; c->last_stream_set = true;
   int rc = ensure_pct_table(c, cfg->score_percent, lmax, s); if (rc != NB_OK) return rc;
   DevIndex ix{c->d_slots, c->d_ctable, c->d_desc, c->d_packed, c->hash, c->chash, c->W, c->K};
   BatchArgs a{};
@@ -1400,11 +1408,25 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   return (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, a, s) : dispatch_se<4, false>(c, nr, positions, ix, a, s);
 }
 
+// Read-backs go through a stream of their own (non-blocking: none of the legacy null stream's implicit synchronisation with every other
+// stream of the process), after waiting for the stream the last batch was launched on — what the synchronous copies used to imply.
+static int readback(nb_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (c->last_stream_set) NB_HIP(hipStreamSynchronize(c->last_stream));
+  for (size_t done = 0; done < bytes;) {                      // device -> pinned staging -> the caller's (pageable) memory
+    const size_t m = std::min(bytes - done, c->h_stage_cap);
+    NB_HIP(hipMemcpyAsync(c->h_stage, static_cast<const char*>(src) + done, m, hipMemcpyDeviceToHost, c->copy_stream));
+    NB_HIP(hipStreamSynchronize(c->copy_stream));
+    std::memcpy(static_cast<char*>(dst) + done, c->h_stage, m);
+    done += m;
+  }
+  return NB_OK;
+}
+
 int32_t nb_classes_count(nb_ctx* c, int64_t* n) {
   if (!c || !n) { set_error("nb_classes_count: null argument"); return NB_ERR_INVALID; }
   NB_HIP(hipSetDevice(c->device));
   unsigned int v = 0, e = 0;
-  NB_HIP(hipMemcpy(&v, c->ct.n_classes, 4, hipMemcpyDeviceToHost)); NB_HIP(hipMemcpy(&e, c->ct.err, 4, hipMemcpyDeviceToHost));
+  { int r = readback(c, &v, c->ct.n_classes, 4); if (r != NB_OK) return r; r = readback(c, &e, c->ct.err, 4); if (r != NB_OK) return r; }
   if (e & 2u) { set_error("class table: publish wait timed out"); return NB_ERR_HIP; }
   if ((e & 1u) || v > (unsigned int)c->max_classes) { set_error("class table overflow: raise max_classes"); return NB_ERR_OVERFLOW; }
   *n = (int64_t)v; return NB_OK;
@@ -1413,23 +1435,38 @@ int32_t nb_classes_count(nb_ctx* c, int64_t* n) {
 // rows of the class table are kept in INTERNAL sequence numbering on the device (nb_internal.h, ColDesc); callers get bitsets over the
 // ORIGINAL sequence indices, words_per_row = ceil(n_seqs / 64) words per row
 static int read_rows_external(nb_ctx* c, int64_t first, int64_t count, uint64_t* rows) {
-  std::vector<uint64_t> tmp((size_t)count * (size_t)c->W);
-  NB_HIP(hipMemcpy(tmp.data(), c->ct.rows + (size_t)first * (size_t)c->W, tmp.size() * 8, hipMemcpyDeviceToHost));
-  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, std::min<int64_t>((int64_t)std::thread::hardware_concurrency(), count * (int64_t)c->W / (1 << 18))));
-  auto work = [&](int64_t lo, int64_t hi) {
-    std::memset(rows + (size_t)lo * (size_t)c->W_ext, 0, (size_t)(hi - lo) * (size_t)c->W_ext * 8);
-    for (int64_t r = lo; r < hi; ++r) {
-      const uint64_t* in = tmp.data() + (size_t)r * (size_t)c->W; uint64_t* out = rows + (size_t)r * (size_t)c->W_ext;
-      for (int w = 0; w < c->W; ++w) for (uint64_t v = in[w]; v; v &= v - 1) {
-          const int32_t o = c->inv_perm[(size_t)w * 64 + (size_t)__builtin_ctzll(v)];
-          if (o >= 0) out[o >> 6] |= 1ull << (o & 63);
-        }
-    }
-  };
-  std::vector<std::thread> th;
-  for (int t = 1; t < T; ++t) th.emplace_back(work, count * t / T, count * (t + 1) / T);
-  work(0, count / T);
-  for (auto& x : th) x.join();
+  // device -> pinned staging buffer of the ctx (whole rows per chunk) -> renumbered into the caller's rows by up to 16 threads
+  const bool timing = std::getenv("NB_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  double t_copy = 0;
+  if (c->last_stream_set) NB_HIP(hipStreamSynchronize(c->last_stream));
+  const int64_t per_chunk = std::max<int64_t>(1, (int64_t)(c->h_stage_cap / ((size_t)c->W * 8)));
+  const uint64_t* tmp = static_cast<const uint64_t*>(c->h_stage);
+  if ((size_t)c->W * 8 > c->h_stage_cap) { set_error("nb_classes_read: a class row is larger than the staging buffer"); return NB_ERR_UNSUPPORTED; }
+  for (int64_t base = 0; base < count; base += per_chunk) {
+    const int64_t m = std::min(per_chunk, count - base);
+    const auto a = std::chrono::steady_clock::now();
+    NB_HIP(hipMemcpyAsync(c->h_stage, c->ct.rows + (size_t)(first + base) * (size_t)c->W, (size_t)m * (size_t)c->W * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    NB_HIP(hipStreamSynchronize(c->copy_stream));
+    t_copy += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, std::min<int64_t>((int64_t)std::thread::hardware_concurrency(), m * (int64_t)c->W / (1 << 16))));
+    auto work = [&](int64_t lo, int64_t hi) {
+      std::memset(rows + (size_t)(base + lo) * (size_t)c->W_ext, 0, (size_t)(hi - lo) * (size_t)c->W_ext * 8);
+      for (int64_t r = lo; r < hi; ++r) {
+        const uint64_t* in = tmp + (size_t)r * (size_t)c->W; uint64_t* out = rows + (size_t)(base + r) * (size_t)c->W_ext;
+        for (int w = 0; w < c->W; ++w) for (uint64_t v = in[w]; v; v &= v - 1) {
+            const int32_t o = c->inv_perm[(size_t)w * 64 + (size_t)__builtin_ctzll(v)];
+            if (o >= 0) out[o >> 6] |= 1ull << (o & 63);
+          }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, m * t / T, m * (t + 1) / T);
+    work(0, m / T);
+    for (auto& x : th) x.join();
+  }
+  if (timing) std::fprintf(stderr, "[nb_classes_read] %lld rows x %d words: %.2f ms, of which copies %.2f ms\n", (long long)count, c->W,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), t_copy);
   return NB_OK;
 }
 
@@ -1438,7 +1475,7 @@ int32_t nb_classes_read(nb_ctx* c, int64_t cap, uint64_t* rows, int64_t* counts)
   if (cap < n) { set_error("nb_classes_read: cap smaller than the number of classes"); return NB_ERR_INVALID; }
   if (n == 0) return NB_OK;
   if (rows) { const int r2 = read_rows_external(c, 0, n, rows); if (r2 != NB_OK) return r2; }
-  if (counts) NB_HIP(hipMemcpy(counts, c->ct.counts, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (counts) { const int r = readback(c, counts, c->ct.counts, (size_t)n * 8); if (r != NB_OK) return r; }
   return NB_OK;
 }
 
@@ -1447,14 +1484,14 @@ int32_t nb_classes_read_range(nb_ctx* c, int64_t first, int64_t count, uint64_t*
   if (first < 0 || count < 0 || first + count > n) { set_error("nb_classes_read_range: range outside the known classes"); return NB_ERR_INVALID; }
   if (count == 0) return NB_OK;
   if (rows) { const int r2 = read_rows_external(c, first, count, rows); if (r2 != NB_OK) return r2; }
-  if (counts) NB_HIP(hipMemcpy(counts, c->ct.counts + first, (size_t)count * 8, hipMemcpyDeviceToHost));
+  if (counts) { const int r = readback(c, counts, c->ct.counts + first, (size_t)count * 8); if (r != NB_OK) return r; }
   return NB_OK;
 }
 
 int32_t nb_reasons_read(nb_ctx* c, int64_t* out) {
   if (!c || !out) { set_error("nb_reasons_read: null argument"); return NB_ERR_INVALID; }
   NB_HIP(hipSetDevice(c->device));
-  NB_HIP(hipMemcpy(out, c->ct.reasons, NB_NUM_REASONS * 8, hipMemcpyDeviceToHost)); return NB_OK;
+  return readback(c, out, c->ct.reasons, NB_NUM_REASONS * 8);
 }
 
 int32_t nb_results_reset(nb_ctx* c, void* stream) {

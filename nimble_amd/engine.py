@@ -178,8 +178,8 @@ class Context:
         n = ct.c_int64()
         check(_lib.lib().nb_classes_count(self._h, ct.byref(n)))
         w = self.index.words
-        rows = np.zeros((n.value, w), dtype=np.uint64)
-        counts = np.zeros(n.value, dtype=np.int64)
+        rows = np.empty((n.value, w), dtype=np.uint64)          # (nb_classes_read fills every word)
+        counts = np.empty(n.value, dtype=np.int64)
         if n.value:
             check(_lib.lib().nb_classes_read(self._h, n.value, rows.ctypes.data_as(_lib.c_u64p), counts.ctypes.data_as(_lib.c_i64p)))
         return rows, counts
