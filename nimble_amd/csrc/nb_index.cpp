@@ -448,13 +448,30 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
           cidx[j] = (uint32_t)(it - canons.begin());             // (every library k-mer is in canons)
         }
       });
-      std::vector<uint32_t> tpos_of((size_t)n_canon, NONE);
-      for (int64_t j = 0; j < T; ++j) { const uint32_t i = cidx[(size_t)j]; if (i != NONE && tpos_of[i] == NONE) tpos_of[i] = (uint32_t)j; }
       auto is_both = [&](uint32_t i) { return canons[i].pay[0] != PAY_ABSENT && canons[i].pay[1] != PAY_ABSENT; };
       std::vector<uint8_t> room((size_t)T + 1, 0);
       for (int64_t j = T - 2; j >= 0; --j) {
         const uint32_t a = cidx[(size_t)j], b = cidx[(size_t)j + 1];
         room[(size_t)j] = (a != NONE && b != NONE && !is_both(b)) ? (uint8_t)std::min<uint32_t>((uint32_t)room[(size_t)j + 1] + 1u, ANCHOR_MAX_ROOM) : (uint8_t)0;
+      }
+      // Which occurrence anchors a k-mer: any would be exact; the walk runs longest along the sequence that most other sequences agree
+      // with (a read leaves its anchor at the READ's private variants either way, and at the ANCHOR's private variants on top): the
+      // occurrence whose next ANCHOR_LOOKAHEAD text k-mers are shared by the most sequences (sum of class sizes), first one on ties.
+      std::vector<uint64_t> ahead((size_t)T + 2, 0);          // prefix sums of the class sizes along the text
+      for (int64_t j = 0; j < T; ++j) {
+        const uint32_t i = cidx[(size_t)j];
+        uint64_t sz = 0;
+        if (i != NONE) { const Canon& cn = canons[i]; sz = ix->eq_sizes[(cn.pay[0] != PAY_ABSENT ? cn.pay[0] : cn.pay[1]) >> 10]; }
+        ahead[(size_t)j + 1] = ahead[(size_t)j] + sz;
+      }
+      std::vector<uint32_t> tpos_of((size_t)n_canon, NONE);
+      std::vector<uint64_t> best((size_t)n_canon, 0);
+      for (int64_t j = 0; j < T; ++j) {
+        const uint32_t i = cidx[(size_t)j];
+        if (i == NONE) continue;
+        const int64_t r = std::min<int64_t>((int64_t)room[(size_t)j], ANCHOR_LOOKAHEAD);
+        const uint64_t score = ahead[(size_t)(j + 1 + r)] - ahead[(size_t)j + 1];
+        if (tpos_of[i] == NONE || score > best[i]) { tpos_of[i] = (uint32_t)j; best[i] = score; }
       }
       // level 0: the class of the k-mer at every text position as NW words from the first word of its sequence's component
       ix->sparse.assign((size_t)ANCHOR_LEVELS * (size_t)T * (size_t)NW, 0ull);

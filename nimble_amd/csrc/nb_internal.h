@@ -144,7 +144,7 @@ NB_HD inline uint32_t ph_slot(const PHProbe& p, uint32_t pilot, const PHash& h) 
 }
 
 // ---- ANCHOR structures of the anchor-extend kernel (nb_anchor.hip): walk a read along the library TEXT instead of looking every k-mer up ----
-// Once a k-mer of the read is known to sit at text position t (a table hit: its entry names ONE occurrence, the first in library order),
+// Once a k-mer of the read is known to sit at text position t (a table hit: its entry names ONE occurrence, chosen by the index builder),
 // the next k-mers of the walk of docs/SPEC.md §3 need no lookup while the read's next bases equal the text's: the (K+1)-mer read[i..i+K]
 // then occurs in the library by construction, so the base is a right extension, the next k-mer is the text's k-mer at t + 1, and its class
 // is a property of the text position. 32 bases are compared per step (XOR of two 64-bit windows), and the AND of the classes of a run of
@@ -168,6 +168,7 @@ constexpr uint32_t ANCHOR_MAX_ROOM = (1u << ANCHOR_LEVELS) - 2;
 constexpr uint32_t ANCHOR_ROOM_MASK = 0x7FFFu;          // AEntry.room: bits [0,15) room, bit 15 ANCHOR_WIDE, bits [16,32) first class-row word of the component
 constexpr uint32_t ANCHOR_WIDE = 1u << 15;              // the anchor sequence's component is wider than the sparse table's entries
 constexpr int64_t ANCHOR_MAX_TEXT = 1ll << 31;
+constexpr int64_t ANCHOR_LOOKAHEAD = 64;                // text k-mers ahead that decide which occurrence of a k-mer becomes its anchor (nb_index.cpp)
 constexpr int64_t ANCHOR_MAX_SPARSE_BYTES = 8ll << 30;  // 8 levels x 8 (16) bytes per library base: libraries up to ~130 (65) M bases
 constexpr int64_t PH_LARGE_MAX_TABLE_BYTES = 4ll << 30; // perfect-hash table with its first level in global memory
 
