@@ -305,7 +305,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       const bool need = active && last >= 0 && !to_scan && !(fl & F_REDO);
 #pragma unroll
       for (int wi = 0; wi < NR; ++wi) {
-        const int res = ((last % 3) - (wi % 3) + 3) % 3;
+        const int res = ((last % 3 + 3) % 3 - (wi % 3) + 3) % 3;           // (last < 0 for reads shorter than k: keep the shift count in range)
         uint64_t m = (PAT << res) & ~cover.w[wi];
         const int top = last - wi * 64;                                       // positions <= last only
         m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
     const uint64_t PAT = 0x9249249249249249ull;
 #pragma unroll
     for (int wi = 0; wi < NR; ++wi) {                                       // p % 3 == 0 (forward seed scan) or p % 3 == last % 3 (the other orientation's)
-      const int r0 = (3 - (wi % 3)) % 3, r1 = ((last % 3) - (wi % 3) + 3) % 3;
+      const int r0 = (3 - (wi % 3)) % 3, r1 = ((last % 3 + 3) % 3 - (wi % 3) + 3) % 3;
       uint64_t m = (PAT << r0) | (PAT << r1);
       const int top = last - wi * 64;
       m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));

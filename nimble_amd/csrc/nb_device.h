@@ -258,6 +258,11 @@ struct LaneLists {
   uint32_t* redo_list;    // reads for the wave-per-read kernel
   uint32_t* counters;     // [0] = entries in rc_list, [1] = entries in redo_list
 };
+// (the only raw ISA string in the per-lane device code; tests/native/anchor_emul.cpp compiles that code for the host and blanks it)
+#ifndef NB_WAIT_VMCNT0
+#define NB_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 // everything the tail of a lane-per-read batch needs (class table, outputs, filters, lists): read from device memory at the point of use
 struct LaneTail { DevClasses ct; BatchArgs a; LaneLists ll; int W; };
 
@@ -291,7 +296,7 @@ __device__ __forceinline__ uint32_t intern_lane2(const DevClasses& ct, int W, bo
               __hip_atomic_store(&ct.rows[(size_t)id * W + w], (unsigned long long)((uint32_t)w == lo ? a0 : ((uint32_t)w == lo + 1u ? a1 : 0ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ct.spans[id], span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            NB_WAIT_VMCNT0();
             __hip_atomic_store(&ct.ids[h], id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             result = id; pending = false;
           }
