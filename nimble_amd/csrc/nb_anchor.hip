@@ -17,6 +17,7 @@
 //             wider than one word — puts the read on the redo list of the wave-per-read kernel, exactly like nb_lane.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -25,6 +26,13 @@
 
 namespace nb {
 
+// Paired templates (SPEC §4): each mate is walked like a single read, but what leaves the kernel is the raw alignment of the orientation
+// that hits — coverage, orientation, the class words — and the guarantee that the other orientation has no hit at all; nb_anchor_pair_kernel
+// combines the two mates of a template. status: 0 = as described, 1 = cannot be settled here (the pair goes to the wave-per-read kernel),
+// 2 = shorter than k, 3 = on the scan list (the scan kernel turns it into 0 with coverage 0, or into 1).
+struct MateRes { uint32_t info, lo; uint64_t a0, a1; };    // info = coverage | orientation << 16 | status << 17
+constexpr uint32_t MATE_OK = 0u, MATE_REDO = 1u, MATE_SHORT = 2u, MATE_SCAN = 3u;
+
 struct AnchorHead {
   const AEntry* table; const uint8_t* pilots; PHash ph; int K;
   const uint32_t* text; const uint64_t* sparse; long long T;
@@ -32,6 +40,7 @@ struct AnchorHead {
   long long n;
   int pilot_lds_bytes, rec_dwords;                   // dynamic LDS: [pilots][per wave: rec_dwords x 64 dwords]
   long long text_words, sparse_words; int W;         // sizes, for the bounds-checked debug build (-DNB_ANCHOR_PROF -DNB_ANCHOR_CHECK)
+  MateRes* mate_out;                                 // MATE kernels: one raw result per sequence instead of SPEC §4 / interning / outputs
 };
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
@@ -112,7 +121,7 @@ __device__ __forceinline__ Look anchor_lookup(const AnchorHead& h, const uint8_t
   return k;
 }
 
-template <int NR, int NW, bool PLDS>
+template <int NR, int NW, bool PLDS, bool MATE>
 __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
@@ -338,71 +347,87 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     }
 
     PROF_MARK(3);
-    // ---- SPEC §4 per lane, outputs, lists ----
-    asm volatile("" ::: "memory");
-    const LaneTail& T = *tp;
-    const BatchArgs& a = T.a;
-    const int pmin = a.lens ? (int)a.pct_min[L] : a.pct_fixed;
-    int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0;
-    uint32_t cls = NB_NO_CLASS;
-    bool to_redo = false, final_ = false, call = false;
-    if (active && L >= K && !to_scan) {
-      if (fl & F_REDO) to_redo = true;
-      else {
-        final_ = true;                                                        // the other orientation has no hit: its coverage is 0 (NO_HIT)
-        if (a.out_cov) a.out_cov[r] = rcf ? ((uint64_t)(cov & 0xFFFF) << 16) : (uint64_t)(cov & 0xFFFF);
-        const int cheapS = cheap_reason_p(cov, pmin, a);
-        const uint32_t n = (uint32_t)__popcll(a0) + (NW > 1 ? (uint32_t)__popcll(a1) : 0u);
-        int rs = 0;
-        if (cheapS != 0) rs = cheapS;
-        else if (n == 0) rs = NB_EMPTY_EQCLASS;
-        else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
-        else if ((rcf && a.strand_filter == NB_STRAND_FIVEPRIME) || (!rcf && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
-        if (rs) reason = rs;
-        else { score = cov; orient = rcf ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
+    if (MATE) {                                                               // paired path: the raw alignment of this mate, no decision here
+      if (active) {
+        uint32_t st = MATE_OK;
+        if (L < K) st = MATE_SHORT; else if (to_scan) st = MATE_SCAN; else if (fl & F_REDO) st = MATE_REDO;
+        MateRes mr; mr.info = (uint32_t)(cov & 0xFFFF) | ((rcf ? 1u : 0u) << 16) | (st << 17); mr.lo = lo; mr.a0 = a0; mr.a1 = NW > 1 ? a1 : 0ull;
+        h.mate_out[r] = mr;
       }
-    } else if (active && !to_scan) { final_ = true; if (a.out_cov) a.out_cov[r] = 0ull; }
-    PROF_MARK(4);
-    // equal result sets inside the wave are interned and counted once: with real data most reads of a batch map to a few classes, and 64
-    // lanes adding to one counter serialise in the L2 (a handful of leader rounds; whoever is left after them goes alone)
-    uint32_t leader = (uint32_t)lane, mult = call ? 1u : 0u;
-    bool lead = call;
-    {
-      uint64_t pendm = __ballot(call);
-      for (int it = 0; it < 6 && pendm; ++it) {
-        const int ld = __builtin_ctzll(pendm);
-        const uint32_t va_lo = __builtin_amdgcn_readlane((uint32_t)a0, ld), va_hi = __builtin_amdgcn_readlane((uint32_t)(a0 >> 32), ld);
-        const uint32_t vl = __builtin_amdgcn_readlane(lo, ld);
-        bool eq = call && (uint32_t)a0 == va_lo && (uint32_t)(a0 >> 32) == va_hi && lo == vl;
-        if (NW > 1) eq = eq && (uint32_t)a1 == (uint32_t)__builtin_amdgcn_readlane((uint32_t)a1, ld) && (uint32_t)(a1 >> 32) == (uint32_t)__builtin_amdgcn_readlane((uint32_t)(a1 >> 32), ld);
-        const uint64_t same = __ballot(eq) & pendm;
-        if ((same >> lane) & 1ull) { leader = (uint32_t)ld; lead = lane == ld; mult = lane == ld ? (uint32_t)__popcll(same) : 0u; }
-        pendm &= ~same;
-      }
-    }
-    if (lead && !CHK(lo < (uint32_t)T.W && (!(NW > 1 && a1) || lo + 1u < (uint32_t)T.W), 14)) lead = false;
-    cls = intern_lane2(T.ct, T.W, lead, lo, a0, NW > 1 ? a1 : 0ull);
-    cls = (uint32_t)__shfl((int)cls, (int)leader);
-    PROF_MARK(5);
-    if (lead && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], (unsigned long long)mult);
-    if (active && final_) {
-      atomicAdd(&s_reason[reason], 1u);
-      if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
-      if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
-    }
-    {   // worklists: wave ballot + prefix count, one atomic per wave and list
-      const uint64_t ms = __ballot(to_scan), mredo = __ballot(to_redo);
+      const uint64_t ms = __ballot(to_scan);
       if (ms) {
         uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&T.ll.counters[0], (uint32_t)__popcll(ms));
+        if (lane == 0) b0 = atomicAdd(&tp->ll.counters[0], (uint32_t)__popcll(ms));
         b0 = __builtin_amdgcn_readfirstlane(b0);
-        if (to_scan) T.ll.rc_list[b0 + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = r;
+        if (to_scan) tp->ll.rc_list[b0 + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = r;
       }
-      if (mredo) {
-        uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
-        b0 = __builtin_amdgcn_readfirstlane(b0);
-        if (to_redo) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+    } else {
+    // ---- SPEC §4 per lane, outputs, lists ----
+      asm volatile("" ::: "memory");
+      const LaneTail& T = *tp;
+      const BatchArgs& a = T.a;
+      const int pmin = a.lens ? (int)a.pct_min[L] : a.pct_fixed;
+      int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0;
+      uint32_t cls = NB_NO_CLASS;
+      bool to_redo = false, final_ = false, call = false;
+      if (active && L >= K && !to_scan) {
+        if (fl & F_REDO) to_redo = true;
+        else {
+          final_ = true;                                                        // the other orientation has no hit: its coverage is 0 (NO_HIT)
+          if (a.out_cov) a.out_cov[r] = rcf ? ((uint64_t)(cov & 0xFFFF) << 16) : (uint64_t)(cov & 0xFFFF);
+          const int cheapS = cheap_reason_p(cov, pmin, a);
+          const uint32_t n = (uint32_t)__popcll(a0) + (NW > 1 ? (uint32_t)__popcll(a1) : 0u);
+          int rs = 0;
+          if (cheapS != 0) rs = cheapS;
+          else if (n == 0) rs = NB_EMPTY_EQCLASS;
+          else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
+          else if ((rcf && a.strand_filter == NB_STRAND_FIVEPRIME) || (!rcf && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
+          if (rs) reason = rs;
+          else { score = cov; orient = rcf ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
+        }
+      } else if (active && !to_scan) { final_ = true; if (a.out_cov) a.out_cov[r] = 0ull; }
+      PROF_MARK(4);
+      // equal result sets inside the wave are interned and counted once: with real data most reads of a batch map to a few classes, and 64
+      // lanes adding to one counter serialise in the L2 (a handful of leader rounds; whoever is left after them goes alone)
+      uint32_t leader = (uint32_t)lane, mult = call ? 1u : 0u;
+      bool lead = call;
+      {
+        uint64_t pendm = __ballot(call);
+        for (int it = 0; it < 6 && pendm; ++it) {
+          const int ld = __builtin_ctzll(pendm);
+          const uint32_t va_lo = __builtin_amdgcn_readlane((uint32_t)a0, ld), va_hi = __builtin_amdgcn_readlane((uint32_t)(a0 >> 32), ld);
+          const uint32_t vl = __builtin_amdgcn_readlane(lo, ld);
+          bool eq = call && (uint32_t)a0 == va_lo && (uint32_t)(a0 >> 32) == va_hi && lo == vl;
+          if (NW > 1) eq = eq && (uint32_t)a1 == (uint32_t)__builtin_amdgcn_readlane((uint32_t)a1, ld) && (uint32_t)(a1 >> 32) == (uint32_t)__builtin_amdgcn_readlane((uint32_t)(a1 >> 32), ld);
+          const uint64_t same = __ballot(eq) & pendm;
+          if ((same >> lane) & 1ull) { leader = (uint32_t)ld; lead = lane == ld; mult = lane == ld ? (uint32_t)__popcll(same) : 0u; }
+          pendm &= ~same;
+        }
+      }
+      if (lead && !CHK(lo < (uint32_t)T.W && (!(NW > 1 && a1) || lo + 1u < (uint32_t)T.W), 14)) lead = false;
+      cls = intern_lane2(T.ct, T.W, lead, lo, a0, NW > 1 ? a1 : 0ull);
+      cls = (uint32_t)__shfl((int)cls, (int)leader);
+      PROF_MARK(5);
+      if (lead && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], (unsigned long long)mult);
+      if (active && final_) {
+        atomicAdd(&s_reason[reason], 1u);
+        if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
+        if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
+      }
+      {   // worklists: wave ballot + prefix count, one atomic per wave and list
+        const uint64_t ms = __ballot(to_scan), mredo = __ballot(to_redo);
+        if (ms) {
+          uint32_t b0 = 0;
+          if (lane == 0) b0 = atomicAdd(&T.ll.counters[0], (uint32_t)__popcll(ms));
+          b0 = __builtin_amdgcn_readfirstlane(b0);
+          if (to_scan) T.ll.rc_list[b0 + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = r;
+        }
+        if (mredo) {
+          uint32_t b0 = 0;
+          if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
+          b0 = __builtin_amdgcn_readfirstlane(b0);
+          if (to_redo) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+        }
       }
     }
     PROF_MARK(6);
@@ -416,7 +441,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
 
 // The reads none of whose three probes was in the table (ll.rc_list): every seed-scan position of BOTH orientations is looked up, all lanes
 // in lock-step, four lookups in flight per lane. No k-mer found at all: NO_HIT in both orientations, final. Anything found: redo list.
-template <int NR, bool PLDS>
+template <int NR, bool PLDS, bool MATE>
 __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_nohit;
@@ -483,23 +508,129 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
         for (int wi = 0; wi < NR; ++wi) todo.w[wi] = 0;
       }
     }
-    const BatchArgs& a = T.a;
-    if (active && !hit) {
-      atomicAdd(&s_nohit, 1u);
-      if (a.out_class) a.out_class[r] = NB_NO_CLASS;
-      if (a.out_info) a.out_info[r] = (uint32_t)NB_NO_HIT << 16;
-      if (a.out_cov) a.out_cov[r] = 0ull;
-    }
-    const uint64_t mredo = __ballot(active && hit);
-    if (mredo) {
-      uint32_t b0 = 0;
-      if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
-      b0 = __builtin_amdgcn_readfirstlane(b0);
-      if (active && hit) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+    if (MATE) {
+      if (active) { MateRes mr; mr.info = (hit ? MATE_REDO : MATE_OK) << 17; mr.lo = 0u; mr.a0 = 0ull; mr.a1 = 0ull; h.mate_out[r] = mr; }
+    } else {
+      const BatchArgs& a = T.a;
+      if (active && !hit) {
+        atomicAdd(&s_nohit, 1u);
+        if (a.out_class) a.out_class[r] = NB_NO_CLASS;
+        if (a.out_info) a.out_info[r] = (uint32_t)NB_NO_HIT << 16;
+        if (a.out_cov) a.out_cov[r] = 0ull;
+      }
+      const uint64_t mredo = __ballot(active && hit);
+      if (mredo) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        if (active && hit) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+      }
     }
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_nohit) atomicAdd(&tp->ct.reasons[NB_NO_HIT], (unsigned long long)s_nohit);
+}
+
+// SPEC §4 for paired templates from the two mates' raw alignments (MateRes): one pair per lane. A mate has ONE orientation with hits (the
+// other is NONE: coverage 0, NO_HIT) or none at all, so the four alignments map(r1), map(rc(r1)), map(r2), map(rc(r2)) are all known; they
+// are checked and combined exactly as nb_align_general_kernel does (evaluate_alignment, combine_mates). Pairs with a mate the anchor
+// kernels could not settle, or whose union would span two separate word ranges (mates on different components), go on the redo list.
+template <int NW>
+__global__ __launch_bounds__(256) void nb_anchor_pair_kernel(const MateRes* __restrict__ m1, const MateRes* __restrict__ m2, int K, const LaneTail* __restrict__ tp) {
+  __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const LaneTail& T = *tp;
+  const BatchArgs& a = T.a;
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  struct Aln { int rs, cov; uint32_t lo; uint64_t s0, s1; };
+  for (long long base = ((long long)blockIdx.x * (blockDim.x >> 6) + wave) * 64; base < a.n; base += nwaves * 64) {
+    const long long r = base + lane;
+    const bool active = r < a.n;
+    MateRes x{}, y{};
+    if (active) { x = m1[r]; y = m2[r]; }
+    const uint32_t st1 = (x.info >> 17) & 3u, st2 = (y.info >> 17) & 3u;
+    bool redo = active && (st1 == MATE_REDO || st1 == MATE_SCAN || st2 == MATE_REDO || st2 == MATE_SCAN);
+    int L1 = 0, L2 = 0;
+    if (active) {
+      L1 = a.lens ? (int)a.lens[r] : a.max_len; if (L1 > a.max_len) L1 = a.max_len;
+      L2 = a.mate_lens ? (int)a.mate_lens[r] : a.mate_max_len; if (L2 > a.mate_max_len) L2 = a.mate_max_len;
+    }
+    // alignment j: 0 = map(r1), 1 = map(rc(r1)), 2 = map(r2), 3 = map(rc(r2))
+    Aln al[4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const MateRes& v = m ? y : x; const int L = m ? L2 : L1;
+      const uint32_t st = m ? st2 : st1; const int o = (int)((v.info >> 16) & 1u), c = (int)(v.info & 0xFFFFu);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        Aln& A = al[2 * m + t];
+        A.cov = 0; A.lo = 0; A.s0 = 0; A.s1 = 0;
+        if (st == MATE_SHORT || L < K) { A.rs = NB_TOO_SHORT; continue; }
+        if (t != o || c == 0) { A.rs = NB_NO_HIT; continue; }                 // the orientation without hits (or a mate without any)
+        A.cov = c; A.lo = v.lo; A.s0 = v.a0; A.s1 = NW > 1 ? v.a1 : 0ull;
+        int rs = cheap_reason_p(c, (int)a.pct_min[L], a);
+        if (!rs) {
+          const uint32_t n = (uint32_t)__popcll(A.s0) + (uint32_t)__popcll(A.s1);
+          if (n == 0) rs = NB_EMPTY_EQCLASS; else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
+        }
+        A.rs = rs;
+      }
+    }
+    struct Ori { bool valid; int reason, score, mates; uint32_t lo; uint64_t s0, s1; };
+    auto combine = [&](const Aln& p, const Aln& q) {                          // p: the r1 member of the orientation, q: the r2 member
+      Ori o{false, p.rs, 0, 0, 0u, 0ull, 0ull};
+      const bool v1 = p.rs == 0, v2 = q.rs == 0;
+      if (v1 && v2) {
+        const bool same = p.lo == q.lo;
+        const uint64_t i0 = same ? (p.s0 & q.s0) : 0ull, i1 = same ? (p.s1 & q.s1) : 0ull;
+        const uint32_t ni = (uint32_t)__popcll(i0) + (uint32_t)__popcll(i1);
+        const bool use_inter = (a.intersect_level == 2) || (a.intersect_level == 1 && ni != 0);
+        if (a.intersect_level == 2 && ni == 0) { o.reason = NB_EMPTY_EQCLASS; return o; }
+        if (!use_inter && !same) redo = true;                                 // a union over two separate word ranges: wave-per-read kernel
+        o.lo = p.lo; o.s0 = use_inter ? i0 : (p.s0 | q.s0); o.s1 = use_inter ? i1 : (p.s1 | q.s1);
+        o.valid = true; o.reason = 0; o.score = p.cov + q.cov; o.mates = 2; return o;
+      }
+      if (v1 || v2) {
+        if (a.require_valid_pair) { o.reason = NB_INVALID_PAIR; return o; }
+        const Aln& w = v1 ? p : q;
+        o.valid = true; o.reason = 0; o.score = w.cov; o.mates = 1; o.lo = w.lo; o.s0 = w.s0; o.s1 = w.s1; return o;
+      }
+      o.reason = p.rs > q.rs ? p.rs : q.rs; return o;
+    };
+    Ori F = combine(al[0], al[3]), R = combine(al[1], al[2]);                 // F = {map(r1), map(rc(r2))}, R = {map(rc(r1)), map(r2)}
+    if (F.valid && a.strand_filter == NB_STRAND_THREEPRIME) { F.valid = false; F.reason = NB_STRAND; }
+    if (R.valid && a.strand_filter == NB_STRAND_FIVEPRIME) { R.valid = false; R.reason = NB_STRAND; }
+    int reason, score = 0, orient = 0, mates = 0;
+    const bool pickR = R.valid && (!F.valid || R.score > F.score);
+    bool call = false;
+    if (F.valid || R.valid) {
+      score = pickR ? R.score : F.score; orient = pickR ? 1 : 0; mates = pickR ? R.mates : F.mates;
+      reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED;
+      call = reason == NB_CALLED;
+    } else reason = F.reason > R.reason ? F.reason : R.reason;
+    const bool fin = active && !redo;
+    const Ori& P = pickR ? R : F;
+    uint32_t cls = intern_lane2(T.ct, T.W, fin && call, P.lo, P.s0, NW > 1 ? P.s1 : 0ull);
+    if (fin && call && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], 1ull);
+    if (fin) {
+      atomicAdd(&s_reason[reason], 1u);
+      if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
+      if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
+      if (a.out_cov) a.out_cov[r] = (uint64_t)(al[0].cov & 0xFFFF) | ((uint64_t)(al[1].cov & 0xFFFF) << 16) | ((uint64_t)(al[2].cov & 0xFFFF) << 32) | ((uint64_t)(al[3].cov & 0xFFFF) << 48);
+    }
+    const uint64_t mredo = __ballot(active && redo);
+    if (mredo) {
+      uint32_t b0 = 0;
+      if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
+      b0 = __builtin_amdgcn_readfirstlane(b0);
+      if (active && redo) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = (uint32_t)r;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
 
 // dynamic LDS of one workgroup: first level of the table (if it fits next to >= 8 waves of records: *plds) + record staging of up to 12
@@ -519,23 +650,33 @@ static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_blo
   return pil + (int64_t)w * rec;
 }
 
-template <int NR, int NW, bool PLDS>
+template <int NR, int NW, bool PLDS, bool MATE>
 static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
-  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
   const long long need = (h.n + 64LL * waves - 1) / (64LL * waves);
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
+  hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
   NB_HIP(hipGetLastError());
-  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR, PLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, PLDS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (list length: on the device)
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, PLDS, MATE>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (list length: on the device)
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
-template <int NR>
+template <int NR, bool MATE>
 static int launch_anchor_n(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, bool plds, hipStream_t s) {
-  if (c->anchor_nw == 1) return plds ? launch_anchor_t<NR, 1, true>(c, h, d_tail, waves, lds, s) : launch_anchor_t<NR, 1, false>(c, h, d_tail, waves, lds, s);
-  return plds ? launch_anchor_t<NR, 2, true>(c, h, d_tail, waves, lds, s) : launch_anchor_t<NR, 2, false>(c, h, d_tail, waves, lds, s);
+  if (c->anchor_nw == 1) return plds ? launch_anchor_t<NR, 1, true, MATE>(c, h, d_tail, waves, lds, s) : launch_anchor_t<NR, 1, false, MATE>(c, h, d_tail, waves, lds, s);
+  return plds ? launch_anchor_t<NR, 2, true, MATE>(c, h, d_tail, waves, lds, s) : launch_anchor_t<NR, 2, false, MATE>(c, h, d_tail, waves, lds, s);
+}
+template <bool MATE>
+static int launch_anchor_nr(nb_ctx* c, int nr, const AnchorHead& h, const LaneTail* dt, int waves, int64_t lds, bool plds, hipStream_t s) {
+  switch (nr) {
+    case 1: return launch_anchor_n<1, MATE>(c, h, dt, waves, lds, plds, s);
+    case 2: return launch_anchor_n<2, MATE>(c, h, dt, waves, lds, plds, s);
+    case 3: return launch_anchor_n<3, MATE>(c, h, dt, waves, lds, plds, s);
+    case 4: return launch_anchor_n<4, MATE>(c, h, dt, waves, lds, plds, s);
+    default: return launch_anchor_n<5, MATE>(c, h, dt, waves, lds, plds, s);
+  }
 }
 
 bool anchor_fits(const nb_ctx* c, int max_len) {
@@ -548,6 +689,13 @@ bool anchor_pilots_in_lds(const nb_ctx* c, int max_len) {
   return anchor_lds_bytes(c, max_len, &w, &plds) > 0 && plds;
 }
 
+static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads, const uint16_t* lens, int max_len, long long n, bool plds, MateRes* mate_out) {
+  const int nwb = (max_len + 31) / 32, nwn = (nwb + 1) >> 1;
+  return AnchorHead{c->d_atable, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
+                    plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
+                    (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out};
+}
+
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
   int waves = 0; bool plds = false;
   const int64_t lds = anchor_lds_bytes(c, a.max_len, &waves, &plds);
@@ -556,19 +704,38 @@ int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, con
   if (!c->d_lane_tail) NB_HIP(hipMalloc((void**)&c->d_lane_tail, sizeof(LaneTail)));
   LaneTail t{c->ct, a, ll, ix.W};
   NB_HIP(hipMemcpyAsync(c->d_lane_tail, &t, sizeof t, hipMemcpyHostToDevice, s));
-  const int nwn = (a.nwb + 1) >> 1;
-  AnchorHead h{c->d_atable, c->d_ph_pilots, c->ph, ix.K, c->d_text, c->d_sparse, c->text_len, a.reads, a.lens, a.max_len, a.stride, a.nwb, a.n,
-               plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (a.nwb + nwn) + 2,
-               (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, ix.W};
-  const LaneTail* dt = (const LaneTail*)c->d_lane_tail;
-  switch (nr) {
-    case 1: return launch_anchor_n<1>(c, h, dt, waves, lds, plds, s);
-    case 2: return launch_anchor_n<2>(c, h, dt, waves, lds, plds, s);
-    case 3: return launch_anchor_n<3>(c, h, dt, waves, lds, plds, s);
-    case 4: return launch_anchor_n<4>(c, h, dt, waves, lds, plds, s);
-    default: return launch_anchor_n<5>(c, h, dt, waves, lds, plds, s);
-  }
+  const AnchorHead h = make_head(c, ix.K, ix.W, a.reads, a.lens, a.max_len, a.n, plds, nullptr);
+  return launch_anchor_nr<false>(c, nr, h, (const LaneTail*)c->d_lane_tail, waves, lds, plds, s);
 }
+
+// Paired templates: both mates through the MATE kernels (raw alignments into mate_res[0 .. n) and mate_res[n .. 2n)), then the pair kernel.
+// ll.redo_list / counters[1] receive the pairs for the wave-per-read (general) kernel.
+int launch_anchor_pairs(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, void* mate_res, hipStream_t s) {
+  if (!c->has_anchor) { set_error("launch_anchor_pairs: no anchor structures"); return NB_ERR_UNSUPPORTED; }
+  MateRes* mr = static_cast<MateRes*>(mate_res);
+  NB_HIP(hipMemsetAsync(ll.counters, 0, 8, s));
+  if (!c->d_lane_tail) NB_HIP(hipMalloc((void**)&c->d_lane_tail, sizeof(LaneTail)));
+  LaneTail t{c->ct, a, ll, ix.W};
+  NB_HIP(hipMemcpyAsync(c->d_lane_tail, &t, sizeof t, hipMemcpyHostToDevice, s));
+  const LaneTail* dt = (const LaneTail*)c->d_lane_tail;
+  for (int m = 0; m < 2; ++m) {
+    const int max_len = m ? a.mate_max_len : a.max_len;
+    int waves = 0; bool plds = false;
+    const int64_t lds = anchor_lds_bytes(c, max_len, &waves, &plds);
+    if (lds <= 0) { set_error("launch_anchor_pairs: shape does not fit"); return NB_ERR_UNSUPPORTED; }
+    const int positions = max_len - ix.K + 1, nr = positions < 1 ? 1 : (positions + 63) / 64;
+    const AnchorHead h = make_head(c, ix.K, ix.W, m ? a.mates : a.reads, m ? a.mate_lens : a.lens, max_len, a.n, plds, mr + (size_t)m * (size_t)a.n);
+    if (m) NB_HIP(hipMemsetAsync(ll.counters, 0, 4, s));                    // the scan list of the second mate starts empty
+    const int rc = launch_anchor_nr<true>(c, nr, h, dt, waves, lds, plds, s);
+    if (rc != NB_OK) return rc;
+  }
+  const long long blocks = std::min<long long>((long long)c->n_cu * 8, (a.n + 255) / 256);
+  if (c->anchor_nw == 1) hipLaunchKernelGGL((nb_anchor_pair_kernel<1>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, mr, mr + a.n, ix.K, dt);
+  else hipLaunchKernelGGL((nb_anchor_pair_kernel<2>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, mr, mr + a.n, ix.K, dt);
+  NB_HIP(hipGetLastError());
+  return NB_OK;
+}
+int64_t anchor_mate_res_bytes() { return (int64_t)sizeof(MateRes); }
 
 }  // namespace nb
 

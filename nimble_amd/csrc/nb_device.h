@@ -330,6 +330,8 @@ struct nb_ctx;
 namespace nb {
 // nb_anchor.hip: the anchor-extend kernel (one launch; what it cannot finish exactly goes on ll.redo_list like the lane path's)
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s);
+int launch_anchor_pairs(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, void* mate_res, hipStream_t s);   // paired templates
+int64_t anchor_mate_res_bytes();                           // bytes of one raw mate result (two per template in mate_res)
 bool anchor_fits(const nb_ctx* c, int max_len);
 bool anchor_pilots_in_lds(const nb_ctx* c, int max_len);   // which instantiation launch_anchor picks (kernel names for the profiles)
 // nb_lane.hip: both lane-per-read passes of one batch, then gather of the redo reads; nb_lane_scatter puts their results back
@@ -351,6 +353,7 @@ struct nb_ctx {
   nb::DevClasses ct{}; nb::DevClasses* d_ct = nullptr; int64_t max_classes = 0;
   // worklists of the lane-per-read path (nb_lane.hip): reads to map in reverse-complement orientation, reads for the wave-per-read kernel
   uint32_t* d_lists = nullptr; int64_t lists_cap = 0; uint32_t* d_list_counters = nullptr; int max_desc_nw = 0;
+  uint64_t* d_redo_mates = nullptr; int64_t redo_mate_words_cap = 0; uint16_t* d_redo_mate_lens = nullptr; void* d_mate_res = nullptr; int64_t mate_res_cap = 0;   // paired path of nb_anchor.hip
   uint64_t* d_redo_reads = nullptr; int64_t redo_words_cap = 0; uint16_t* d_redo_lens = nullptr; uint32_t* d_redo_out = nullptr;   // gathered redo reads + their results (4 u32 per read)
   void* d_lane_tail = nullptr;     // LaneTail of the current batch (nb_lane.hip)
   nb::PHEntry* d_ph_table = nullptr; uint8_t* d_ph_pilots = nullptr; nb::PHash ph{}; bool has_ph = false;   // perfect-hash table of the lane kernels

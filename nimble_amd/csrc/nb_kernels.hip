@@ -942,7 +942,8 @@ __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevC
   uint64_t* seq = s_seq[MODE == 0 ? wave : 0];
   const bool paired = a.mates != nullptr;
   const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  for (long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave; r < a.n; r += nwaves) {
+  const long long n_items = a.n_dev ? (long long)*a.n_dev : a.n;   // (redo list of the paired anchor path: the count lives on the device)
+  for (long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave; r < n_items; r += nwaves) {
     int L1 = a.lens ? (int)a.lens[r] : a.max_len; if (L1 > a.max_len) L1 = a.max_len;
     int L2 = 0;
     if (paired) { L2 = a.mate_lens ? (int)a.mate_lens[r] : a.mate_max_len; if (L2 > a.mate_max_len) L2 = a.mate_max_len; }
@@ -1151,7 +1152,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_lane_tail); if (c->h_stage) (void)hipHostFree(c->h_stage); if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) (void)hipHostFree(c->h_stage); if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
@@ -1395,6 +1396,47 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     if (c->compact) rc = (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, b, s) : dispatch_se<4, true>(c, nr, positions, ix, b, s);
     else rc = (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, b, s) : dispatch_se<4, false>(c, nr, positions, ix, b, s);   // (anchors next to the wide table)
     if (rc != NB_OK) return rc;
+    BatchArgs sc = a; sc.n = c->lists_cap;
+    return launch_lane_scatter(c, sc, ll, c->d_redo_out, s);
+  }
+  // Paired templates in exact mode, index with anchor structures: each mate through the anchor kernels (raw alignments), SPEC §4 for the
+  // pair in nb_anchor_pair_kernel; pairs it cannot settle are gathered and go through the general kernel below (nb_anchor.hip).
+  if (d_mates && cfg->num_mismatches == 0 && c->has_anchor && !(anchor_env && anchor_env[0] == '0') && !(lane_env && lane_env[0] == '0') && n < (1ll << 31) &&
+      max_len >= c->K && mate_max_len >= c->K && anchor_fits(c, max_len) && anchor_fits(c, mate_max_len)) {
+    if (c->lists_cap < n) {
+      (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;
+      NB_HIP(hipMalloc((void**)&c->d_lists, (size_t)n * 2 * 4)); NB_HIP(hipMalloc((void**)&c->d_redo_lens, (size_t)n * 2)); NB_HIP(hipMalloc((void**)&c->d_redo_out, (size_t)n * 16));
+      c->lists_cap = n; c->mate_res_cap = 0;                                   // (d_redo_mate_lens follows lists_cap)
+    }
+    if (c->mate_res_cap < n) {
+      (void)hipFree(c->d_mate_res); (void)hipFree(c->d_redo_mate_lens); c->d_mate_res = nullptr; c->d_redo_mate_lens = nullptr;
+      NB_HIP(hipMalloc(&c->d_mate_res, (size_t)n * 2 * (size_t)anchor_mate_res_bytes())); NB_HIP(hipMalloc((void**)&c->d_redo_mate_lens, (size_t)c->lists_cap * 2));
+      c->mate_res_cap = n;
+    }
+    if (c->redo_words_cap < n * (int64_t)a.stride) {
+      (void)hipFree(c->d_redo_reads); c->d_redo_reads = nullptr;
+      NB_HIP(hipMalloc((void**)&c->d_redo_reads, (size_t)(n * a.stride) * 8)); c->redo_words_cap = n * a.stride;
+    }
+    if (c->redo_mate_words_cap < n * (int64_t)a.mstride) {
+      (void)hipFree(c->d_redo_mates); c->d_redo_mates = nullptr;
+      NB_HIP(hipMalloc((void**)&c->d_redo_mates, (size_t)(n * a.mstride) * 8)); c->redo_mate_words_cap = n * a.mstride;
+    }
+    if (!c->d_list_counters) NB_HIP(hipMalloc((void**)&c->d_list_counters, 8));
+    LaneLists ll{c->d_lists, c->d_lists + c->lists_cap, c->d_list_counters};
+    rc = launch_anchor_pairs(c, ix, a, ll, c->d_mate_res, s); if (rc != NB_OK) return rc;
+    c->last_kernels = "nb_anchor_kernel<mates>;nb_anchor_scan_kernel<mates>;nb_anchor_pair_kernel";
+    rc = launch_lane_gather(c, a, ll, c->d_redo_reads, c->d_redo_lens, s); if (rc != NB_OK) return rc;
+    BatchArgs am = a; am.reads = a.mates; am.lens = a.mate_lens; am.stride = a.mstride;
+    rc = launch_lane_gather(c, am, ll, c->d_redo_mates, c->d_redo_mate_lens, s); if (rc != NB_OK) return rc;
+    BatchArgs b = a;
+    b.reads = c->d_redo_reads; b.lens = a.lens ? c->d_redo_lens : nullptr; b.mates = c->d_redo_mates; b.mate_lens = a.mate_lens ? c->d_redo_mate_lens : nullptr;
+    b.n_dev = c->d_list_counters + 1;
+    b.out_class = a.out_class ? c->d_redo_out : nullptr; b.out_info = a.out_info ? c->d_redo_out + c->lists_cap : nullptr;
+    b.out_cov = a.out_cov ? reinterpret_cast<uint64_t*>(c->d_redo_out + 2 * c->lists_cap) : nullptr;
+    if (c->compact) rc = (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, true, ix, b, s) : dispatch_general<4, true>(c, nr, positions, true, ix, b, s);
+    else rc = (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, true, ix, b, s) : dispatch_general<4, false>(c, nr, positions, true, ix, b, s);
+    if (rc != NB_OK) return rc;
+    c->last_kernels = "nb_anchor_kernel<mates>;nb_anchor_scan_kernel<mates>;nb_anchor_pair_kernel;" + c->last_kernels;
     BatchArgs sc = a; sc.n = c->lists_cap;
     return launch_lane_scatter(c, sc, ll, c->d_redo_out, s);
   }

@@ -42,7 +42,7 @@ static void run_kernels(const AnchorHead& h, const LaneTail* tail, int waves, lo
     for (long long b = 0; b < blocks; ++b)
       for (int w = 0; w < waves; ++w) {
         blockIdx = dim3((unsigned)b); threadIdx = dim3((unsigned)(64 * w));     // lane 0 of wave w
-        if (pass == 0) nb_anchor_kernel<NR, NW, false>(h, tail); else nb_anchor_scan_kernel<NR, false>(h, tail);
+        if (pass == 0) nb_anchor_kernel<NR, NW, false, false>(h, tail); else nb_anchor_scan_kernel<NR, false, false>(h, tail);
       }
   }
 }

@@ -165,3 +165,28 @@ def test_component_wider_than_the_sparse_entries(built):
     reads += [strs[5][10:110], rc(strs[5][5:105]), strs[80][0:100]]
     ora = _check(strs, 20, reads, 100, "wide component")
     assert (ora["reason"] == 0).mean() > 0.4
+
+
+@pytest.mark.parametrize("alleles,kw", [(8, dict()), (8, dict(intersect_level=1, strand_filter="fiveprime")), (8, dict(intersect_level=2, require_valid_pair=True)),
+                                        (8, dict(discard_multiple_matches=True)), (80, dict()), (80, dict(intersect_level=1))])
+def test_paired_templates(built, alleles, kw):
+    """Paired templates in exact mode: each mate through the anchor kernels (raw alignments), SPEC §4 for the pair in nb_anchor_pair_kernel;
+    junk mates, mates from another locus (a union over two components: general kernel), ragged lengths, two-word classes (80-allele loci)."""
+    from oracle import oracle
+    from tests.test_general_gpu import synth_pairs
+    _, seqs, strs, _ = library_strings(3, alleles, locus_len=500, seed=31)
+    c1, c2 = synth_pairs(seqs, 3000, 100, 91, seed=5)
+    r1 = ["".join("ACGTN"[c] for c in row) for row in c1]
+    r2 = ["".join("ACGTN"[c] for c in row) for row in c2]
+    rng = np.random.default_rng(1)
+    for j in range(0, 3000, 11):
+        r1[j] = r1[j][:int(rng.integers(0, 100))]
+        r2[(j * 7) % 3000] = r2[(j * 7) % 3000][:int(rng.integers(10, 91))]
+    cfg = engine.make_config(**kw)
+    w1, l1 = engine.pack_reads(r1, 100)
+    w2, l2 = engine.pack_reads(r2, 91)
+    gpu = run_gpu(engine.Index(strs, 20), cfg, w1, l1, 100, mate_words=w2, mate_lens=l2, mate_max_len=91)
+    assert any(name.startswith("nb_anchor_pair_kernel") for name in gpu["kernels"]), gpu["kernels"]
+    ora = oracle.OracleIndex(strs, 20).align_strs(cfg, r1, r2, n_threads=8)
+    assert (ora["mates"] == 2).sum() > 300
+    assert_same(gpu, ora, f"paired templates {alleles} {kw}")
