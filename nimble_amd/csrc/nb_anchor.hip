@@ -371,6 +371,10 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       uint32_t cls = NB_NO_CLASS;
       bool to_redo = false, final_ = false, call = false;
       if (active && L >= K && !to_scan) {
+#if defined(NB_ANCHOR_PROF) && !defined(NB_ANCHOR_CHECK)
+        PROF_COUNT(10, __popcll(__ballot((fl & F_HARD) != 0))); PROF_COUNT(11, __popcll(__ballot((fl & F_OPP) != 0))); PROF_COUNT(12, __popcll(__ballot((fl & F_LEXT) != 0)));
+        PROF_COUNT(13, __popcll(__ballot((fl & F_SLOW) != 0))); PROF_COUNT(14, __popcll(__ballot((fl & F_REDO) != 0)));
+#endif
         if (fl & F_REDO) to_redo = true;
         else {
           final_ = true;                                                        // the other orientation has no hit: its coverage is 0 (NO_HIT)

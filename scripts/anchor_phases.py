@@ -41,4 +41,5 @@ v = np.array(list(buf), dtype=np.float64)
 tot = v[:7].sum()
 for name, x in zip(("stage", "probes+rc", "rounds", "other-strand scan", "decide", "intern", "outputs+lists"), v[:7]):
     print(f"{name:20s} {100 * x / tot:6.2f} %   {x / max(v[9], 1):10.0f} cycles per wave-batch")
+print("redo flags (reads): both-strand k-mer %d, opposite-strand hit %d, left extension %d, wide component %d, any %d" % tuple(int(x) for x in v[10:15]))
 print(f"rounds per wave-batch: {v[8] / max(v[9], 1):.1f}; wave-batches: {int(v[9])}; kernels: {ctx.last_kernels()}")
