@@ -282,6 +282,7 @@ __device__ __forceinline__ uint32_t intern_lane2(const DevClasses& ct, int W, bo
   for (uint32_t it = 0; it < (1u << 24) && __ballot(pending); ++it) {
     if (pending) {
       const uint64_t cur = __hip_atomic_load(&ct.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t idp0 = __hip_atomic_load(&ct.ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // fetched with the key: one round trip on the common (already interned) path
       if (cur == 0) {
         unsigned long long expected = 0ull;
         __hip_atomic_compare_exchange_strong(&ct.keys[h], &expected, (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -303,7 +304,7 @@ __device__ __forceinline__ uint32_t intern_lane2(const DevClasses& ct, int W, bo
         }
         // lost the race: look at the same slot again in the next iteration (its key is set now)
       } else if (cur == key) {
-        const uint32_t idp = __hip_atomic_load(&ct.ids[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t idp = idp0;                    // (an id still 0 here is polled again in the next iteration, with a fresh load)
         if (idp == 0xFFFFFFFFu) pending = false;      // table overflow recorded by the owner
         else if (idp != 0u) {
           const uint32_t id = idp - 1u;

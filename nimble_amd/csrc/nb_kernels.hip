@@ -1384,7 +1384,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     LaneLists ll{c->d_lists, c->d_lists + c->lists_cap, c->d_list_counters};
     rc = use_anchor ? launch_anchor(c, nr, ix, a, ll, s) : launch_lane(c, nr, ix, a, ll, s); if (rc != NB_OK) return rc;
     { char buf[160];
-      if (use_anchor) std::snprintf(buf, sizeof buf, "nb_anchor_kernel<%d, %d, %s>;nb_anchor_scan_kernel<%d, %s>", nr > 5 ? 5 : nr, c->anchor_nw, anchor_pilots_in_lds(c, max_len) ? "true" : "false",
+      if (use_anchor) std::snprintf(buf, sizeof buf, "nb_anchor_kernel<%d, %d, %s, false>;nb_anchor_scan_kernel<%d, %s, false>", nr > 5 ? 5 : nr, c->anchor_nw, anchor_pilots_in_lds(c, max_len) ? "true" : "false",
                                     nr > 5 ? 5 : nr, anchor_pilots_in_lds(c, max_len) ? "true" : "false");
       else std::snprintf(buf, sizeof buf, "nb_lane_kernel<%d, 0>;nb_lane_kernel<%d, 1>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr);
       c->last_kernels = buf; }
