@@ -7,14 +7,22 @@
 // and the AND of the classes of the k-mers passed comes from the sparse table with two loads. A lookup happens only where the read leaves
 // its anchor sequence or where the walk has to seed:
 //
-//   round     every lane holds one pending lookup: SEEK (seed scan, stride 3) or STEP (the k-mer that ends at the base where the last run
-//             stopped: the walk goes on iff it is in the table on the stream strand and the base before it is one of its left extensions —
-//             the same (K+1)-mer test as nb_lane.hip). A successful lookup is followed by the run along the text.
+//   record    each lane stages its packed read in its own LDS column; a read that maps in reverse-complement orientation (three probes
+//             decide) rewrites the column IN PLACE as the reverse complement, so every later access is a plain 32-base window (Rec).
+//   round     a lane is in SEEK (seed scan, stride 3), STEP (the k-mer that ends at the base where the last run stopped: the walk goes
+//             on iff it is in the table on the stream strand and the base before it is one of its left extensions — the same (K+1)-mer
+//             test as nb_lane.hip), EXT (following the text) or done: at most one lookup and one 32-base comparison per round.
 //   other     SPEC §4 needs the coverage of the OTHER orientation too. It is zero unless one of that orientation's seed-scan positions
 //   strand    (stream positions p = last, last - 3, ...) hits on the opposite strand. Positions inside verified runs cannot (runs never
-//             enter k-mers that occur on both strands); the remaining ones are looked up after the walk, four in flight per lane.
-//   redo      anything else — a k-mer on both strands, any opposite-strand hit, a first seed at or beyond L/5 (left extension), a class
-//             wider than one word — puts the read on the redo list of the wave-per-read kernel, exactly like nb_lane.hip.
+//             enter k-mers that occur on both strands); the remaining ones are looked up after the walk, eight in flight per lane.
+//   scan      a read none of whose probes is in the table at all is settled by nb_anchor_scan_kernel: every seed-scan position of both
+//             orientations, all lanes busy; nothing found = NO_HIT.
+//   redo      anything else — a k-mer on both strands, any opposite-strand hit, a first seed at or beyond L/5 (left extension), an
+//             anchor in a component wider than the sparse table's entries — puts the read on the redo list of the wave-per-read kernel.
+//   pairs     MATE form of both kernels + nb_anchor_pair_kernel: SPEC §4 for paired templates from the two mates' raw alignments.
+// Classes of one or two 64-bit words (NW); first level of the perfect hash in LDS or, for large libraries, read from L2 (PLDS).
+// Debug builds: -DNB_ANCHOR_PROF (phase clock, scripts/anchor_phases.py), -DNB_ANCHOR_CHECK (bounds-checked, scripts/anchor_check.py);
+// the same device code runs on the CPU with one lane per wave under ASan / UBSan (tests/native/anchor_emul.cpp).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
