@@ -190,3 +190,27 @@ def test_paired_templates(built, alleles, kw):
     ora = oracle.OracleIndex(strs, 20).align_strs(cfg, r1, r2, n_threads=8)
     assert (ora["mates"] == 2).sum() > 300
     assert_same(gpu, ora, f"paired templates {alleles} {kw}")
+
+
+@pytest.mark.parametrize("env,kernel", [(("NB_ANCHOR", "0"), "nb_lane_kernel"), (("NB_LANE", "0"), "nb_align_se_kernel")])
+def test_fallback_kernels_stay_exact(built, monkeypatch, env, kernel):
+    """The kernels behind the anchor path are still product code (indexes without anchor structures: k > 23, a library whose components are
+    mostly wider than two words, HBM too short for the sparse table): the lane-per-read kernels (NB_ANCHOR=0) and the wave-per-read kernel
+    alone (NB_LANE=0) on the 1 000-sequence library, single-end and paired."""
+    from oracle import oracle
+    from tests.test_general_gpu import synth_pairs
+    monkeypatch.setenv(*env)
+    _, seqs, strs, _ = library_strings(20, 50)
+    codes = synth.synth_reads(seqs, 12000, 150, seed=21)
+    cfg = engine.make_config()
+    index = engine.Index(strs, 20)
+    gpu = run_gpu(index, cfg, synth.pack_codes(codes), None, 150)
+    assert gpu["kernels"][0].startswith(kernel), gpu["kernels"]
+    blob, off = synth.reads_to_ascii(codes)
+    ox = oracle.OracleIndex(strs, 20)
+    assert_same(gpu, ox.align(cfg, blob, off, n_threads=8), f"single-end {env}")
+    c1, c2 = synth_pairs(seqs, 3000, 100, 91, seed=8)
+    gpu = run_gpu(index, cfg, synth.pack_codes(c1), None, 100, mate_words=synth.pack_codes(c2), mate_max_len=91)
+    assert gpu["kernels"][0].startswith("nb_align_general_kernel"), gpu["kernels"]
+    b1, o1 = synth.reads_to_ascii(c1); b2, o2 = synth.reads_to_ascii(c2)
+    assert_same(gpu, ox.align(cfg, b1, o1, b2, o2, n_threads=8), f"pairs {env}")
