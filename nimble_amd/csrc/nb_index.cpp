@@ -6,6 +6,7 @@
 // array is sorted, and colours / extension masks fall out of a single grouped pass. The result is the flat
 // canonical-k-mer table the kernels probe plus the colour bitset rows.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -334,6 +335,11 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
   //     load per lookup, but ~25 lookups per read instead of one per position).
   const char* ph_env = std::getenv("NB_PH");
   const bool dbg = std::getenv("NB_INDEX_DEBUG") != nullptr;
+  auto tick = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (dbg) { const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[nb_index] %-28s %.2f s\n", what, std::chrono::duration<double>(now - tick).count()); tick = now; }
+  };
+  lap("up to the k-mer table");
   if (dbg) std::fprintf(stderr, "[nb_index] k=%d max_comp_words=%d max_desc_nw=%d n_canon=%lld\n", k, ix->max_comp_words, ix->max_desc_nw, (long long)n_canon);
   if (k <= COMPACT_MAX_K && !(ph_env && ph_env[0] == '0')) {
     static const uint32_t PMULS[2] = {0x9E3779B1u, 0x85EBCA77u};
@@ -411,6 +417,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       ix->has_ph = true; ix->ph = h; ix->ph_table.swap(tab); ix->ph_pilots.swap(pilots);
     }
 
+    lap("perfect hash");
     // 5c. anchor structures of the anchor-extend kernel (nb_internal.h): text, per-k-mer anchor (first occurrence) + room, sparse AND table
     const char* an_env = std::getenv("NB_ANCHOR");
     int64_t T = 0;
@@ -464,6 +471,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         if (i != NONE) { const Canon& cn = canons[i]; sz = ix->eq_sizes[(cn.pay[0] != PAY_ABSENT ? cn.pay[0] : cn.pay[1]) >> 10]; }
         ahead[(size_t)j + 1] = ahead[(size_t)j] + sz;
       }
+      lap("text, k-mer of every position");
       std::vector<uint32_t> tpos_of((size_t)n_canon, NONE);
       std::vector<uint64_t> best((size_t)n_canon, 0);
       for (int64_t j = 0; j < T; ++j) {
@@ -473,8 +481,10 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         const uint64_t score = ahead[(size_t)(j + 1 + r)] - ahead[(size_t)j + 1];
         if (tpos_of[i] == NONE || score > best[i]) { tpos_of[i] = (uint32_t)j; best[i] = score; }
       }
+      lap("anchors");
       // level 0: the class of the k-mer at every text position as NW words from the first word of its sequence's component
       ix->sparse.assign((size_t)ANCHOR_LEVELS * (size_t)T * (size_t)NW, 0ull);
+      lap("  sparse: allocate + zero");
       parallel_ranges((size_t)T, threads, [&](size_t lo, size_t hi) {
         for (size_t j = lo; j < hi; ++j) {
           const uint32_t i = cidx[j];
@@ -489,6 +499,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
           if (d.nw > 1 && d.w0 + 1 >= base && d.w0 + 1 - base < (uint32_t)NW) e[d.w0 + 1 - base] = d.m1;
         }
       });
+      lap("  sparse: level 0");
       for (int l = 1; l < ANCHOR_LEVELS; ++l) {
         const uint64_t* prev = ix->sparse.data() + (size_t)(l - 1) * (size_t)T * (size_t)NW; uint64_t* cur = ix->sparse.data() + (size_t)l * (size_t)T * (size_t)NW;
         const int64_t half = 1ll << (l - 1);
@@ -497,6 +508,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
             cur[j * (size_t)NW + (size_t)w] = ((int64_t)j + half < T) ? (prev[j * (size_t)NW + (size_t)w] & prev[(j + (size_t)half) * (size_t)NW + (size_t)w]) : 0ull;
         });
       }
+      lap("sparse table");
       ix->atable.assign(ix->ph_table.size(), AEntry{0xFFFFFFFFu, PAY_ABSENT, 0u, 0u});
       bool fits = true;
       for (int64_t i = 0; i < n_canon; ++i) {
@@ -509,6 +521,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         const uint32_t wide = (t != NONE && (int)ix->comp_nw[seq_at[t]] > NW) ? ANCHOR_WIDE : 0u;
         ix->atable[slot] = AEntry{pe.key, pe.pay, t == NONE ? 0u : t, ((t == NONE || is_both((uint32_t)i)) ? 0u : (uint32_t)room[t]) | wide | (base << 16)};
       }
+      lap("anchor entries");
       ix->has_anchor = fits;
       if (!fits) { std::vector<AEntry>().swap(ix->atable); std::vector<uint64_t>().swap(ix->sparse); std::vector<uint32_t>().swap(ix->text); }
     }
