@@ -186,3 +186,43 @@ def check_fullsize_properties(index, strs, cfg, d_reads, first_codes, L, max_cla
     flipped = ((info_rc >> 24) & 1) != ((info >> 24) & 1)
     assert flipped[reason == 0].mean() > 0.999          # ties between strands (both orientations equal) are the only exceptions
     return {"called_frac": float(a["reasons"][0]) / n, "sample_sets": sets}
+
+
+def weird_scenario(seed):
+    """A small library + reads built to be awkward for a kernel that follows the library text: homopolymers, short tandem repeats, palindromes
+    (k-mers equal to their reverse complement), duplicated and nested sequences, Ns, sequences barely longer than k, reads that hop between
+    sequences, reads made of a repeat unit. Returns (k, strs, reads, max_len)."""
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([5, 8, 11, 15, 20, 23]))
+    def rnd(n):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    comp = str.maketrans("ACGTN", "TGCAN")
+    base = rnd(int(rng.integers(3 * k, 160)))
+    pal = rnd(k // 2 + 3); pal = pal + pal.translate(comp)[::-1]
+    unit = rnd(int(rng.integers(1, 7)))
+    strs = [base, base[:len(base) // 2] + rnd(3) + base[len(base) // 2:], rnd(30) + pal + rnd(30), rnd(10) + unit * (2 * k) + rnd(10),
+            "A" * (k + int(rng.integers(0, 30))) + rnd(40), rnd(k + 1), base, rnd(50) + "N" + rnd(50) + "NN" + rnd(k), base[5:5 + 2 * k],
+            rnd(60).translate(comp)[::-1]]
+    if rng.random() < 0.5:
+        strs.append(strs[2].translate(comp)[::-1])                         # a reverse-complemented copy: k-mers on both strands
+    max_len = int(rng.choice([k + 3, 40, 77, 131]))
+    max_len = max(max_len, k + 1)
+    reads = []
+    for _ in range(160):
+        kind = rng.random()
+        if kind < 0.55:
+            s = strs[rng.integers(0, len(strs))]; L = int(rng.integers(0, min(len(s), max_len) + 1)); o = int(rng.integers(0, len(s) - L + 1)); r = s[o:o + L]
+        elif kind < 0.75:
+            a, b = strs[rng.integers(0, len(strs))], strs[rng.integers(0, len(strs))]; c = int(rng.integers(0, max_len)); r = (a[-c:] if c else "") + b
+        elif kind < 0.85:
+            r = unit * max_len
+        else:
+            r = rnd(int(rng.integers(0, max_len + 1)))
+        r = list(r[:max_len])
+        for j in range(len(r)):
+            x = rng.random()
+            if x < 0.02: r[j] = "ACGT"[rng.integers(0, 4)]
+            elif x < 0.03: r[j] = "N"
+        r = "".join(r)
+        reads.append(r if rng.random() < 0.5 else r.translate(comp)[::-1])
+    return k, strs, reads, max_len

@@ -102,3 +102,17 @@ def test_both_strands_and_repeats(built, emul, tmp_path):
     strs.append("".join("ACGT"[c] for c in rng.integers(0, 4, 70)) + unit * 5 + "".join("ACGT"[c] for c in rng.integers(0, 4, 90)))
     reads = _reads_from(strs, 900, 120, seed=8, ragged=True)
     _run(emul, tmp_path, strs, 20, reads, 120, engine.make_config(), 0.60)                 # (many reads touch both-strand k-mers: redo list)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_awkward_libraries(built, emul, tmp_path, seed):
+    """Homopolymers, tandem repeats, palindromes, duplicated / nested / reverse-complemented sequences, Ns, k from 5 to 23, reads that hop
+    between sequences (tests.helpers.weird_scenario): whatever the kernels finish themselves equals the oracle, under the sanitizers."""
+    from tests.helpers import weird_scenario
+    k, strs, reads, max_len = weird_scenario(seed)
+    try:
+        _run(emul, tmp_path, strs, k, reads, max_len, engine.make_config(k=k, score_threshold=k, score_filter=k + 2), 1.0)
+    except AssertionError as e:
+        if "no anchor structures" in str(e):
+            pytest.skip("library without anchor structures (most of it on both strands / wide components)")
+        raise

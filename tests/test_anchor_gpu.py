@@ -214,3 +214,22 @@ def test_fallback_kernels_stay_exact(built, monkeypatch, env, kernel):
     assert gpu["kernels"][0].startswith("nb_align_general_kernel"), gpu["kernels"]
     b1, o1 = synth.reads_to_ascii(c1); b2, o2 = synth.reads_to_ascii(c2)
     assert_same(gpu, ox.align(cfg, b1, o1, b2, o2, n_threads=8), f"pairs {env}")
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_awkward_libraries(built, seed):
+    """The scenarios of tests/test_anchor_emul_cpu.py::test_awkward_libraries (and three times as many seeds) on the GPU, every read checked
+    (the redo list included); every fourth scenario as paired templates (reads i and i + 80 as mates)."""
+    from oracle import oracle
+    from tests.helpers import weird_scenario
+    k, strs, reads, max_len = weird_scenario(seed)
+    cfg = engine.make_config(k=k, score_threshold=k, score_filter=k + 2)
+    words, lens = engine.pack_reads(reads, max_len)
+    if seed % 4 == 3:
+        r1, r2 = reads[:80], reads[80:]
+        w1, l1 = engine.pack_reads(r1, max_len); w2, l2 = engine.pack_reads(r2, max_len)
+        gpu = run_gpu(engine.Index(strs, k), cfg, w1, l1, max_len, mate_words=w2, mate_lens=l2, mate_max_len=max_len)
+        assert_same(gpu, oracle.OracleIndex(strs, k).align_strs(cfg, r1, r2, n_threads=4), f"awkward library {seed}, paired (k={k}, kernels {gpu['kernels']})")
+        return
+    gpu = run_gpu(engine.Index(strs, k), cfg, words, lens, max_len)
+    assert_same(gpu, oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=4), f"awkward library {seed} (k={k}, kernels {gpu['kernels']})")
