@@ -243,6 +243,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
 #pragma unroll
     for (int wi = 0; wi < NR; ++wi) cover.w[wi] = 0;
     const int L5 = L / 5;
+    int ls_q = 0, ls_room = 0; uint32_t ls_t = 0;   // first seed with a possible left extension: its position, anchor and left room
     int rounds = 0;
     while (__ballot(mode != DONE)) {
       if (__ballot(mode == SEEK || mode == STEP)) {
@@ -264,7 +265,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         fl |= (both ? F_HARD : 0u) | ((found && !both && !hS) ? F_OPP : 0u);
         const bool ok = hS && (!step || ((pay >> (4u + pb)) & 1u));
         if (ok) {
-          if (!step && !(fl & F_SEEDED) && q >= L5 && q > 0) fl |= F_LEXT;    // the first seed may have a left extension: wave-per-read kernel
+          if (!step && !(fl & F_SEEDED) && q >= L5 && q > 0) {                // the first seed may have a left extension (SPEC §3): after the rounds
+            fl |= F_LEXT; ls_q = q; ls_t = k.e.z; ls_room = (int)((k.e.w >> 8) & 0x7Fu);
+          }
           fl = (fl & ~F_STEP) | (step ? F_STEP : 0u) | F_SEEDED;
           run_t = k.e.z; run_w0 = k.e.w >> 16; run_q = q; steps = 0;
           fl |= (k.e.w & ANCHOR_WIDE) ? F_SLOW : 0u;                          // a component wider than the sparse table's entries: wave-per-read kernel
@@ -312,6 +315,50 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     if (__ballot(p_n != 0u)) {
       uint64_t s0 = ~0ull, s1 = ~0ull;
       if (p_n != 0u) { range_and(p_t, p_n, s0, s1); fold(s0, s1, p_w0); }
+    }
+    // ---- left extension from the first seed (SPEC §3), the common shape: the read follows the anchor's text to the left for a few bases and
+    // then stops at a base that no sequence continues with (the sequencing error that killed the earlier seeds), at an N, or at its own
+    // start. One comparison, one lookup (the left-extension mask of the k-mer at which the comparison stopped), one AND; if some sequence
+    // does continue there, the read stays with the wave-per-read kernel. ----
+    if (__ballot((fl & F_REDO) == F_LEXT)) {
+      const bool le = (fl & F_REDO) == F_LEXT;
+      int lm = 0; bool verify = false, solved = false;
+      if (le) {
+        const int s0 = ls_q > 32 ? ls_q - 32 : 0, na = ls_q - s0;                               // stream bases [s0, ls_q)
+        uint64_t sw; uint32_t sn; R.get32(s0, sw, sn);
+        const uint32_t t0 = ls_t > 32u ? ls_t - 32u : 0u; const int nb = (int)(ls_t - t0);       // text bases [t0, ls_t)
+        const U3 tw3 = *reinterpret_cast<const U3*>(h.text + (t0 >> 4));
+        const uint32_t sh = 2u * (t0 & 15u);
+        const uint64_t t01 = ((uint64_t)tw3.b << 32) | tw3.a;
+        const uint64_t tw = sh ? ((t01 >> sh) | ((uint64_t)tw3.c << (64u - sh))) : t01;
+        // align both windows so that the base just left of the seed sits in the top two bits, then count equal bases from the top
+        const uint64_t swt = sw << (2 * (32 - na)), twt = nb ? (tw << (2 * (32 - nb))) : ~swt;
+        const uint64_t df = swt ^ twt;
+        const uint64_t mm = (df | (df << 1)) & 0xAAAAAAAAAAAAAAAAull;
+        const int lead = mm ? (__builtin_clzll(mm) >> 1) : 32;
+        const uint32_t snt = na < 32 ? (sn << (32 - na)) : sn;                                  // N bits of [s0, ls_q), the last one on top
+        const int leadn = snt ? __builtin_clz(snt) : 32;
+        int cap = na < nb ? na : nb; cap = cap < ls_room ? cap : ls_room; cap = cap < 31 ? cap : 31;
+        lm = lead < leadn ? lead : leadn; lm = lm < cap ? lm : cap;
+        const int r = ls_q - 1 - lm;                                                            // the base the extension stopped at
+        if (r < 0 || leadn == lm) solved = true;                                                // the start of the read, or an N: SPEC's loop ends
+        else verify = true;                                                                     // does ANY sequence continue with that base?
+      }
+      if (__ballot(verify)) {
+        const int qy = ls_q - lm;                                                               // k-mer where the text was left (a text k-mer, on this strand)
+        uint64_t w; uint32_t nn; R.get32(verify ? qy - 1 : 0, w, nn);                           // its window, one base earlier for the candidate left extension
+        const uint32_t cb = (uint32_t)w & 3u;
+        const Look k = anchor_lookup<PLDS>(h, s_pilots, (w >> 2) & kmask, verify);
+        const uint32_t d = k.e.x ^ k.want;
+        const bool mine = verify && d < 4u && !(d & 2u) && ((d & 1u) == (k.o ? 1u : 0u));
+        if (verify && mine && !((k.e.y >> (4u + cb)) & 1u)) solved = true;                      // nobody continues with that base: the extension ends here
+        // (somebody does — another sequence, or this one beyond the left room / the 31 bases compared: the wave-per-read kernel walks it)
+      }
+      if (__ballot(solved && lm > 0)) {
+        uint64_t s0v = ~0ull, s1v = ~0ull;
+        if (solved && lm > 0) { range_and(ls_t - (uint32_t)lm, (uint32_t)lm, s0v, s1v); fold(s0v, s1v, lo); cov += lm; }
+      }
+      if (solved) fl &= ~F_LEXT;
     }
     PROF_MARK(2); PROF_COUNT(8, rounds); PROF_COUNT(9, 1);
 

@@ -461,6 +461,11 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         const uint32_t a = cidx[(size_t)j], b = cidx[(size_t)j + 1];
         room[(size_t)j] = (a != NONE && b != NONE && !is_both(b)) ? (uint8_t)std::min<uint32_t>((uint32_t)room[(size_t)j + 1] + 1u, ANCHOR_MAX_ROOM) : (uint8_t)0;
       }
+      std::vector<uint8_t> lroom((size_t)T + 1, 0);          // the same towards the left (SPEC 3's left extension from the first seed)
+      for (int64_t j = 1; j < T; ++j) {
+        const uint32_t a = cidx[(size_t)j], b = cidx[(size_t)j - 1];
+        lroom[(size_t)j] = (a != NONE && b != NONE && !is_both(b)) ? (uint8_t)std::min<uint32_t>((uint32_t)lroom[(size_t)j - 1] + 1u, ANCHOR_MAX_LROOM) : (uint8_t)0;
+      }
       // Which occurrence anchors a k-mer: any would be exact; the walk runs longest along the sequence that most other sequences agree
       // with (a read leaves its anchor at the READ's private variants either way, and at the ANCHOR's private variants on top): the
       // occurrence whose next ANCHOR_LOOKAHEAD text k-mers are shared by the most sequences (sum of class sizes), first one on ties.
@@ -519,7 +524,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         const uint32_t base = t == NONE ? 0u : ix->comp_w0[seq_at[t]];
         if (base > 0xFFFFu) fits = false;
         const uint32_t wide = (t != NONE && (int)ix->comp_nw[seq_at[t]] > NW) ? ANCHOR_WIDE : 0u;
-        ix->atable[slot] = AEntry{pe.key, pe.pay, t == NONE ? 0u : t, ((t == NONE || is_both((uint32_t)i)) ? 0u : (uint32_t)room[t]) | wide | (base << 16)};
+        ix->atable[slot] = AEntry{pe.key, pe.pay, t == NONE ? 0u : t, ((t == NONE || is_both((uint32_t)i)) ? 0u : ((uint32_t)room[t] | ((uint32_t)lroom[t] << 8))) | wide | (base << 16)};
       }
       lap("anchor entries");
       ix->has_anchor = fits;

@@ -155,7 +155,8 @@ NB_HD inline uint32_t ph_slot(const PHProbe& p, uint32_t pilot, const PHash& h) 
 //             N is stored as A and never compared: `room` stops a run before it
 //   AEntry    same slot, key and pay as the PHEntry of the k-mer (same PHash, same pilots); tpos = text position of the anchor
 //             occurrence; room (low 16 bits) = how many times the walk may step to the NEXT text k-mer from there: the following k-mers
-//             are valid (no N, same sequence), do not occur on both strands, and the run stays below 2^ANCHOR_LEVELS positions; bit 15 =
+//             are valid (no N, same sequence), do not occur on both strands, and the run stays below 2^ANCHOR_LEVELS positions; bits [8, 15)
+//             = the same towards the PREVIOUS text k-mers (left extension from the first seed, at most 127); bit 15 =
 //             the component of the anchor sequence spans more class-row words than a sparse-table entry holds (the read is then mapped
 //             by the wave-per-read kernel); the high 16 bits = first class-row word of that component
 //   sparse    level l, position t: AND of the classes of the k-mers at text positions [t, t + 2^l), as NW = anchor_nw words (1 or 2)
@@ -165,7 +166,8 @@ struct AEntry { uint32_t key, pay, tpos, room; };
 static_assert(sizeof(AEntry) == 16, "anchor entry must be 16 bytes");
 constexpr int ANCHOR_LEVELS = 8;                        // runs of up to 255 k-mer positions
 constexpr uint32_t ANCHOR_MAX_ROOM = (1u << ANCHOR_LEVELS) - 2;
-constexpr uint32_t ANCHOR_ROOM_MASK = 0x7FFFu;          // AEntry.room: bits [0,15) room, bit 15 ANCHOR_WIDE, bits [16,32) first class-row word of the component
+constexpr uint32_t ANCHOR_ROOM_MASK = 0xFFu;            // AEntry.room: bits [0,8) room, [8,15) left room, bit 15 ANCHOR_WIDE, bits [16,32) first class-row word of the component
+constexpr uint32_t ANCHOR_MAX_LROOM = 127u;             // left room: how many times the LEFT extension of SPEC 3 may step to the previous text k-mer (same rules as room)
 constexpr uint32_t ANCHOR_WIDE = 1u << 15;              // the anchor sequence's component is wider than the sparse table's entries
 constexpr int64_t ANCHOR_MAX_TEXT = 1ll << 31;
 constexpr int64_t ANCHOR_LOOKAHEAD = 64;                // text k-mers ahead that decide which occurrence of a k-mer becomes its anchor (nb_index.cpp)
