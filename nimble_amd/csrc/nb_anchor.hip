@@ -49,6 +49,8 @@ struct AnchorHead {
   int pilot_lds_bytes, rec_dwords;                   // dynamic LDS: [pilots][per wave: rec_dwords x 64 dwords]
   long long text_words, sparse_words; int W;         // sizes, for the bounds-checked debug build (-DNB_ANCHOR_PROF -DNB_ANCHOR_CHECK)
   MateRes* mate_out;                                 // MATE kernels: one raw result per sequence instead of SPEC §4 / interning / outputs
+  uint32_t* scan_counts; long long scan_seg;         // scan list: workgroup b owns entries [b * scan_seg, ...) of ll.rc_list and counts them in
+                                                     // scan_counts[b] (one LDS atomic per wave instead of one contended device atomic)
 };
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
@@ -133,12 +135,14 @@ template <int NR, int NW, bool PLDS, bool MATE>
 __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  __shared__ unsigned int s_scan_n;
   uint8_t* s_pilots = s_dyn;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wpb = (int)(blockDim.x >> 6);
   uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_scan_n = 0;
   if (PLDS)
     for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
       *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
@@ -412,9 +416,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       const uint64_t ms = __ballot(to_scan);
       if (ms) {
         uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&tp->ll.counters[0], (uint32_t)__popcll(ms));
+        if (lane == 0) b0 = atomicAdd(&s_scan_n, (uint32_t)__popcll(ms));
         b0 = __builtin_amdgcn_readfirstlane(b0);
-        if (to_scan) tp->ll.rc_list[b0 + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = r;
+        if (to_scan) tp->ll.rc_list[(size_t)blockIdx.x * (size_t)h.scan_seg + b0 + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = r;
       }
     } else {
     // ---- SPEC §4 per lane, outputs, lists ----
@@ -477,9 +481,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
         const uint64_t ms = __ballot(to_scan), mredo = __ballot(to_redo);
         if (ms) {
           uint32_t b0 = 0;
-          if (lane == 0) b0 = atomicAdd(&T.ll.counters[0], (uint32_t)__popcll(ms));
+          if (lane == 0) b0 = atomicAdd(&s_scan_n, (uint32_t)__popcll(ms));
           b0 = __builtin_amdgcn_readfirstlane(b0);
-          if (to_scan) T.ll.rc_list[b0 + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = r;
+          if (to_scan) T.ll.rc_list[(size_t)blockIdx.x * (size_t)h.scan_seg + b0 + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = r;
         }
         if (mredo) {
           uint32_t b0 = 0;
@@ -495,6 +499,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
   if (lane == 0) for (int i = 0; i < 16; ++i) if (pacc[i]) atomicAdd(&g_anchor_prof[i], pacc[i]);
 #endif
   __syncthreads();
+  if (threadIdx.x == 0) h.scan_counts[blockIdx.x] = s_scan_n;
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
 
@@ -510,21 +515,21 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
   const int wpb = (int)(blockDim.x >> 6);
   uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
   const LaneTail& T = *tp;
-  const long long count = (long long)T.ll.counters[0];
+  const long long count = (long long)h.scan_counts[blockIdx.x];                // this workgroup's segment of the scan list (written by the same block index)
+  const uint32_t* __restrict__ seg = T.ll.rc_list + (size_t)blockIdx.x * (size_t)h.scan_seg;
   if (threadIdx.x == 0) s_nohit = 0;
   if (PLDS && count > 0)
     for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
       *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
   __syncthreads();
-  const long long nwaves = (long long)gridDim.x * wpb;
   const int K = h.K;
   const uint64_t kmask = (1ull << (2 * K)) - 1;
   const uint32_t nkmask = (1u << K) - 1u;
   const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1;
-  for (long long base = ((long long)blockIdx.x * wpb + wave) * 64; base < count; base += nwaves * 64) {
+  for (long long base = (long long)wave * 64; base < count; base += (long long)wpb * 64) {
     const long long idx = base + lane;
     const bool active = idx < count;
-    const uint32_t r = active ? T.ll.rc_list[idx] : 0u;
+    const uint32_t r = active ? seg[idx] : 0u;
     int L = 0;
     if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
     Rec R{rec + lane, 2 * nwb, 2 * nwn, L};
@@ -710,15 +715,19 @@ static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_blo
 }
 
 template <int NR, int NW, bool PLDS, bool MATE>
-static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
+static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
   NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
-  const long long need = (h.n + 64LL * waves - 1) / (64LL * waves);
+  const long long need = (h_in.n + 64LL * waves - 1) / (64LL * waves);
   if (blocks > need) blocks = need;
-  hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
+  if (blocks < 1) blocks = 1;
+  AnchorHead h = h_in;                                               // scan-list segment of a workgroup: as many entries as it has reads
+  h.scan_seg = ((h.n + blocks * waves * 64 - 1) / (blocks * waves * 64)) * waves * 64;
+  if (blocks * h.scan_seg > c->scan_list_cap || blocks > c->scan_counts_cap) { set_error("launch_anchor: scan list too small"); return NB_ERR_INVALID; }
+  hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
   NB_HIP(hipGetLastError());
   NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, PLDS, MATE>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (list length: on the device)
+  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (same grid: block b scans block b's segment)
   NB_HIP(hipGetLastError());
   return NB_OK;
 }
@@ -752,7 +761,7 @@ static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads
   const int nwb = (max_len + 31) / 32, nwn = (nwb + 1) >> 1;
   return AnchorHead{c->d_atable, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
-                    (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out};
+                    (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out, c->d_scan_counts, 0};
 }
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {

@@ -354,6 +354,7 @@ struct nb_ctx {
   nb::DevClasses ct{}; nb::DevClasses* d_ct = nullptr; int64_t max_classes = 0;
   // worklists of the lane-per-read path (nb_lane.hip): reads to map in reverse-complement orientation, reads for the wave-per-read kernel
   uint32_t* d_lists = nullptr; int64_t lists_cap = 0; uint32_t* d_list_counters = nullptr; int max_desc_nw = 0;
+  uint32_t* d_scan_counts = nullptr; int64_t scan_counts_cap = 0, scan_list_cap = 0;   // anchor kernels: per-workgroup counts / capacity of the segmented scan list
   uint64_t* d_redo_mates = nullptr; int64_t redo_mate_words_cap = 0; uint16_t* d_redo_mate_lens = nullptr; void* d_mate_res = nullptr; int64_t mate_res_cap = 0;   // paired path of nb_anchor.hip
   uint64_t* d_redo_reads = nullptr; int64_t redo_words_cap = 0; uint16_t* d_redo_lens = nullptr; uint32_t* d_redo_out = nullptr;   // gathered redo reads + their results (4 u32 per read)
   void* d_lane_tail = nullptr;     // LaneTail of the current batch (nb_lane.hip)

@@ -1152,7 +1152,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) (void)hipHostFree(c->h_stage); if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_scan_counts); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) (void)hipHostFree(c->h_stage); if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
@@ -1373,15 +1373,18 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     const int64_t stride = a.stride;
     if (c->lists_cap < n) {
       (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;
-      NB_HIP(hipMalloc((void**)&c->d_lists, (size_t)n * 2 * 4)); NB_HIP(hipMalloc((void**)&c->d_redo_lens, (size_t)n * 2)); NB_HIP(hipMalloc((void**)&c->d_redo_out, (size_t)n * 16));
+      // [redo list: n][scan / reverse list: n + one batch per wave of slack: the anchor kernels give every workgroup its own segment of it]
+      c->scan_list_cap = n + (int64_t)c->n_cu * 12 * 64;
+      NB_HIP(hipMalloc((void**)&c->d_lists, (size_t)(n + c->scan_list_cap) * 4)); NB_HIP(hipMalloc((void**)&c->d_redo_lens, (size_t)n * 2)); NB_HIP(hipMalloc((void**)&c->d_redo_out, (size_t)n * 16));
       c->lists_cap = n;
     }
+    if (!c->d_scan_counts) { NB_HIP(hipMalloc((void**)&c->d_scan_counts, (size_t)c->n_cu * 4)); c->scan_counts_cap = c->n_cu; }
     if (c->redo_words_cap < n * stride) {
       (void)hipFree(c->d_redo_reads); c->d_redo_reads = nullptr;
       NB_HIP(hipMalloc((void**)&c->d_redo_reads, (size_t)(n * stride) * 8)); c->redo_words_cap = n * stride;
     }
     if (!c->d_list_counters) NB_HIP(hipMalloc((void**)&c->d_list_counters, 8));
-    LaneLists ll{c->d_lists, c->d_lists + c->lists_cap, c->d_list_counters};
+    LaneLists ll{c->d_lists + c->lists_cap, c->d_lists, c->d_list_counters};
     rc = use_anchor ? launch_anchor(c, nr, ix, a, ll, s) : launch_lane(c, nr, ix, a, ll, s); if (rc != NB_OK) return rc;
     { char buf[160];
       if (use_anchor) std::snprintf(buf, sizeof buf, "nb_anchor_kernel<%d, %d, %s, false>;nb_anchor_scan_kernel<%d, %s, false>", nr > 5 ? 5 : nr, c->anchor_nw, anchor_pilots_in_lds(c, max_len) ? "true" : "false",
@@ -1405,9 +1408,11 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
       max_len >= c->K && mate_max_len >= c->K && anchor_fits(c, max_len) && anchor_fits(c, mate_max_len)) {
     if (c->lists_cap < n) {
       (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;
-      NB_HIP(hipMalloc((void**)&c->d_lists, (size_t)n * 2 * 4)); NB_HIP(hipMalloc((void**)&c->d_redo_lens, (size_t)n * 2)); NB_HIP(hipMalloc((void**)&c->d_redo_out, (size_t)n * 16));
+      c->scan_list_cap = n + (int64_t)c->n_cu * 12 * 64;
+      NB_HIP(hipMalloc((void**)&c->d_lists, (size_t)(n + c->scan_list_cap) * 4)); NB_HIP(hipMalloc((void**)&c->d_redo_lens, (size_t)n * 2)); NB_HIP(hipMalloc((void**)&c->d_redo_out, (size_t)n * 16));
       c->lists_cap = n; c->mate_res_cap = 0;                                   // (d_redo_mate_lens follows lists_cap)
     }
+    if (!c->d_scan_counts) { NB_HIP(hipMalloc((void**)&c->d_scan_counts, (size_t)c->n_cu * 4)); c->scan_counts_cap = c->n_cu; }
     if (c->mate_res_cap < n) {
       (void)hipFree(c->d_mate_res); (void)hipFree(c->d_redo_mate_lens); c->d_mate_res = nullptr; c->d_redo_mate_lens = nullptr;
       NB_HIP(hipMalloc(&c->d_mate_res, (size_t)n * 2 * (size_t)anchor_mate_res_bytes())); NB_HIP(hipMalloc((void**)&c->d_redo_mate_lens, (size_t)c->lists_cap * 2));
@@ -1422,7 +1427,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
       NB_HIP(hipMalloc((void**)&c->d_redo_mates, (size_t)(n * a.mstride) * 8)); c->redo_mate_words_cap = n * a.mstride;
     }
     if (!c->d_list_counters) NB_HIP(hipMalloc((void**)&c->d_list_counters, 8));
-    LaneLists ll{c->d_lists, c->d_lists + c->lists_cap, c->d_list_counters};
+    LaneLists ll{c->d_lists + c->lists_cap, c->d_lists, c->d_list_counters};
     rc = launch_anchor_pairs(c, ix, a, ll, c->d_mate_res, s); if (rc != NB_OK) return rc;
     c->last_kernels = "nb_anchor_kernel<mates>;nb_anchor_scan_kernel<mates>;nb_anchor_pair_kernel";
     rc = launch_lane_gather(c, a, ll, c->d_redo_reads, c->d_redo_lens, s); if (rc != NB_OK) return rc;

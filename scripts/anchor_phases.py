@@ -15,10 +15,11 @@ from nimble_amd import _build, _lib, engine, synth  # noqa: E402
 _build.build(force=True)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 loci, alleles = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (20, 50)
+read_len = int(sys.argv[4]) if len(sys.argv) > 4 else 150
 names, seqs, _ = synth.synth_library(loci, alleles)
 strs = [synth.codes_to_str(s) for s in seqs]
 dev = torch.device("cuda:0")
-reads = synth.synth_reads_packed_torch(seqs, n, 150, 2, dev)
+reads = synth.synth_reads_packed_torch(seqs, n, read_len, 2, dev)
 ix = engine.Index(strs, 20)
 ctx = engine.Context(0, max_classes=1 << 20)
 ctx.upload(ix)
@@ -32,7 +33,7 @@ for it in range(3):
     ctx.reset()
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
-    ctx.align_batch(cfg, reads, None, 150, oc, oi, None, n=n)
+    ctx.align_batch(cfg, reads, None, read_len, oc, oi, None, n=n)
     t1.record()
     ctx.sync()
     assert fn(buf) == 0

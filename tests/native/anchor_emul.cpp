@@ -31,20 +31,14 @@ using namespace nb;
 template <class T> static T rd(FILE* f) { T v; if (std::fread(&v, sizeof v, 1, f) != 1) { std::fprintf(stderr, "short input\n"); std::exit(2); } return v; }
 
 template <int NR, int NW>
-static void run_kernels(const AnchorHead& h, const LaneTail* tail, int waves, long long blocks) {
-  blockDim = dim3((unsigned)(64 * waves)); gridDim = dim3((unsigned)blocks);
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1) {     // the scan kernel takes list entry (base + lane): spread the dense list so that every entry is some wave's lane 0
-      uint32_t* list = tail->ll.rc_list; uint32_t& cnt = tail->ll.counters[0];
-      for (long long i = (long long)cnt - 1; i >= 0; --i) { const uint32_t v = list[i]; list[i] = 0; list[64 * i] = v; }
-      cnt *= 64;
+static void run_kernels(const AnchorHead& h, const LaneTail* tail, long long blocks) {
+  // one wave per workgroup, one lane per wave: block b maps read 64 * b, then (second pass) scans its own segment of the scan list
+  blockDim = dim3(64); gridDim = dim3((unsigned)blocks); threadIdx = dim3(0);
+  for (int pass = 0; pass < 2; ++pass)
+    for (long long b = 0; b < blocks; ++b) {
+      blockIdx = dim3((unsigned)b);
+      if (pass == 0) nb_anchor_kernel<NR, NW, false, false>(h, tail); else nb_anchor_scan_kernel<NR, false, false>(h, tail);
     }
-    for (long long b = 0; b < blocks; ++b)
-      for (int w = 0; w < waves; ++w) {
-        blockIdx = dim3((unsigned)b); threadIdx = dim3((unsigned)(64 * w));     // lane 0 of wave w
-        if (pass == 0) nb_anchor_kernel<NR, NW, false, false>(h, tail); else nb_anchor_scan_kernel<NR, false, false>(h, tail);
-      }
-  }
 }
 
 int main(int argc, char** argv) {
@@ -87,11 +81,12 @@ int main(int argc, char** argv) {
   a.out_class = out_class.data(); a.out_info = out_info.data(); a.out_cov = out_cov.data(); a.pct_min = pct.data(); a.pct_fixed = pct[(size_t)max_len];
   LaneLists ll{lists.data(), lists.data() + n_emul, counters.data()};
   LaneTail tail{ct, a, ll, W};
+  std::vector<uint32_t> scan_counts((size_t)n_reads, 0);
   AnchorHead h{ix->atable.data(), ix->ph_pilots.data(), ix->ph, k, ix->text.data(), ix->sparse.data(), (long long)ix->text_len, reads.data(), lens.data(), max_len, stride, nwb,
-               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W};
+               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, scan_counts.data(), 64};
   const int positions = max_len - k + 1, nr = positions < 1 ? 1 : (positions + 63) / 64;
-  const int waves = 4; const long long blocks = (n_reads + waves - 1) / waves;
-#define RUN(NR) (ix->anchor_nw == 1 ? run_kernels<NR, 1>(h, &tail, waves, blocks) : run_kernels<NR, 2>(h, &tail, waves, blocks))
+  const long long blocks = n_reads;
+#define RUN(NR) (ix->anchor_nw == 1 ? run_kernels<NR, 1>(h, &tail, blocks) : run_kernels<NR, 2>(h, &tail, blocks))
   switch (nr) { case 1: RUN(1); break; case 2: RUN(2); break; case 3: RUN(3); break; case 4: RUN(4); break; default: RUN(5); break; }
   if (err) { std::fprintf(stderr, "class table error %u\n", err); return 5; }
 
@@ -119,7 +114,8 @@ int main(int argc, char** argv) {
     std::fwrite(rec, 4, 5, o); std::fwrite(&out_cov[r], 8, 1, o); std::fwrite(set.data(), 8, (size_t)words, o);
   }
   std::fclose(o);
-  std::printf("reads %d, scan list %u, redo list %u, classes %u\n", n_reads, counters[0] / 64, counters[1], n_classes);
+  uint32_t n_scan = 0; for (uint32_t v : scan_counts) n_scan += v;
+  std::printf("reads %d, scan list %u, redo list %u, classes %u\n", n_reads, n_scan, counters[1], n_classes);
   delete ix;
   return 0;
 }
