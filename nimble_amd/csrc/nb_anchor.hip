@@ -42,7 +42,7 @@ struct MateRes { uint32_t info, lo; uint64_t a0, a1; };    // info = coverage | 
 constexpr uint32_t MATE_OK = 0u, MATE_REDO = 1u, MATE_SHORT = 2u, MATE_SCAN = 3u;
 
 struct AnchorHead {
-  const AEntry* table; const uint8_t* pilots; PHash ph; int K;
+  const AEntry* table; const uint32_t* keys; const uint8_t* pilots; PHash ph; int K;     // keys[slot] = table[slot].key (presence / strand tests)
   const uint32_t* text; const uint64_t* sparse; long long T;
   const uint64_t* reads; const uint16_t* lens; int max_len, stride, nwb;
   long long n;
@@ -131,6 +131,21 @@ __device__ __forceinline__ Look anchor_lookup(const AnchorHead& h, const uint8_t
   return k;
 }
 
+// presence / strand test only: the key word of the slot, from the 4-byte-per-slot copy (a quarter of the table: stays in the L2s)
+struct LookKey { uint32_t d; bool o; };         // d = key ^ want: < 4 = the k-mer is in the table; bit 1 = on both strands; bit 0 ^ o = on the other strand
+template <bool PLDS>
+__device__ __forceinline__ LookKey anchor_lookup_key(const AnchorHead& h, const uint8_t* s_pilots, uint64_t x, bool valid) {
+  const uint64_t y = rc_kmer(x, h.K);
+  LookKey k; k.o = x > y;
+  const PHProbe pr = ph_probe(k.o ? y : x, h.ph);
+  const bool gok = CHK(pr.group < h.ph.n_groups, 10);
+  const uint32_t pilot = PLDS ? (uint32_t)s_pilots[gok ? pr.group : 0u] : ((valid && gok) ? (uint32_t)h.pilots[pr.group] : 0u);
+  uint32_t slot = valid ? ph_slot(pr, pilot, h.ph) : 0u;
+  if (!CHK(slot < h.ph.n_slots, 11)) slot = 0u;
+  k.d = h.keys[slot] ^ pr.want;
+  return k;
+}
+
 template <int NR, int NW, bool PLDS, bool MATE>
 __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -195,17 +210,17 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
     // probes is in the table at all is most likely foreign to the library: the scan kernel settles it (no walk, no divergence here) ----
     if (last >= 0) {
       int votes = 0; bool any = false;
-      Look pk[3]; bool pv[3];
+      LookKey pk[3]; bool pv[3];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int p = u == 0 ? 0 : (u == 1 ? last >> 1 : last);
         uint64_t w; uint32_t nn; R.get32(p, w, nn);
         pv[u] = (nn & nkmask) == 0;
-        pk[u] = anchor_lookup<PLDS>(h, s_pilots, w & kmask, pv[u]);
+        pk[u] = anchor_lookup_key<PLDS>(h, s_pilots, w & kmask, pv[u]);
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        const uint32_t d = pk[u].e.x ^ pk[u].want;
+        const uint32_t d = pk[u].d;
         if (pv[u] && d < 4u) { any = true; if (!(d & 2u)) votes += ((d & 1u) == (pk[u].o ? 1u : 0u)) ? 1 : -1; }
       }
       rcf = votes < 0;
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       }
       while (__ballot(any_set<NR>(todo))) {
         constexpr int U = 8;
-        Look kk[U]; bool vv[U];
+        LookKey kk[U]; bool vv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int p = -1;
@@ -389,11 +404,11 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
           for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
           uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
           vv[u] = p >= 0 && (nn & nkmask) == 0;
-          kk[u] = anchor_lookup<PLDS>(h, s_pilots, w & kmask, vv[u]);
+          kk[u] = anchor_lookup_key<PLDS>(h, s_pilots, w & kmask, vv[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const uint32_t d = kk[u].e.x ^ kk[u].want;
+          const uint32_t d = kk[u].d;
           const bool found = vv[u] && d < 4u;
           const bool mine = found && !(d & 2u) && ((d & 1u) == (kk[u].o ? 1u : 0u));
           if (found && !mine) fl |= F_OPP;
@@ -555,7 +570,7 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
     bool hit = false;
     while (__ballot(any_set<NR>(todo))) {
       constexpr int U = 8;
-      Look kk[U]; bool vv[U];
+      LookKey kk[U]; bool vv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int p = -1;
@@ -563,10 +578,10 @@ __global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const
         for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
         uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
         vv[u] = p >= 0 && (nn & nkmask) == 0;
-        kk[u] = anchor_lookup<PLDS>(h, s_pilots, w & kmask, vv[u]);
+        kk[u] = anchor_lookup_key<PLDS>(h, s_pilots, w & kmask, vv[u]);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) hit = hit || (vv[u] && ((kk[u].e.x ^ kk[u].want) < 4u));
+      for (int u = 0; u < U; ++u) hit = hit || (vv[u] && kk[u].d < 4u);
       if (hit) {
 #pragma unroll
         for (int wi = 0; wi < NR; ++wi) todo.w[wi] = 0;
@@ -759,7 +774,7 @@ bool anchor_pilots_in_lds(const nb_ctx* c, int max_len) {
 
 static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads, const uint16_t* lens, int max_len, long long n, bool plds, MateRes* mate_out) {
   const int nwb = (max_len + 31) / 32, nwn = (nwb + 1) >> 1;
-  return AnchorHead{c->d_atable, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
+  return AnchorHead{c->d_atable, c->d_akeys, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
                     (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out, c->d_scan_counts, 0};
 }

@@ -526,9 +526,11 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
         const uint32_t wide = (t != NONE && (int)ix->comp_nw[seq_at[t]] > NW) ? ANCHOR_WIDE : 0u;
         ix->atable[slot] = AEntry{pe.key, pe.pay, t == NONE ? 0u : t, ((t == NONE || is_both((uint32_t)i)) ? 0u : ((uint32_t)room[t] | ((uint32_t)lroom[t] << 8))) | wide | (base << 16)};
       }
+      ix->akeys.resize(ix->atable.size());
+      for (size_t i = 0; i < ix->atable.size(); ++i) ix->akeys[i] = ix->atable[i].key;
       lap("anchor entries");
       ix->has_anchor = fits;
-      if (!fits) { std::vector<AEntry>().swap(ix->atable); std::vector<uint64_t>().swap(ix->sparse); std::vector<uint32_t>().swap(ix->text); }
+      if (!fits) { std::vector<uint32_t>().swap(ix->akeys); std::vector<AEntry>().swap(ix->atable); std::vector<uint64_t>().swap(ix->sparse); std::vector<uint32_t>().swap(ix->text); }
     }
   }
   ix->n_canonical = n_canon;

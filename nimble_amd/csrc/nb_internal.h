@@ -226,6 +226,8 @@ struct HostIndex {
   int64_t text_len = 0;               // bases in `text`
   std::vector<uint32_t> text;         // text_len bases + 64 bases of padding
   std::vector<AEntry> atable;         // ph.n_slots entries, slot for slot the k-mers of ph_table
+  std::vector<uint32_t> akeys;        // the key words of atable alone (4 bytes per slot): what a presence / strand test needs (probes, the
+                                      // other-orientation check, the scan kernel) from an array a quarter the size of the table
   std::vector<uint64_t> sparse;       // ANCHOR_LEVELS * text_len words
   int max_desc_nw = 1;                // widest class span in words (1 = every class inside one word: the lane-per-read kernels apply)
   std::vector<int32_t> perm;          // original sequence index -> internal bit position

@@ -1153,7 +1153,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
   (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_scan_counts); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) (void)hipHostFree(c->h_stage); if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-  (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
+  (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_akeys); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
 
@@ -1177,8 +1177,8 @@ int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
   s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = h.compact ? (int64_t)h.ctable.size() * 2 : (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
   s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
   s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0; s->words_internal = h.words_dev; s->ph_table_bytes = (int64_t)(h.ph_table.size() * sizeof(PHEntry)); s->ph_pilot_bytes = (int64_t)h.ph_pilots.size();
-  s->anchor_bytes = (int64_t)(h.atable.size() * sizeof(AEntry) + h.text.size() * 4 + h.sparse.size() * 8);
-  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.text.size() * 4 + h.sparse.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
+  s->anchor_bytes = (int64_t)(h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8);
+  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
   return NB_OK;
 }
 
@@ -1273,18 +1273,19 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
     NB_HIP(hipMemcpy(c->d_ph_table, h.ph_table.data(), h.ph_table.size() * sizeof(PHEntry), hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(c->d_ph_pilots, h.ph_pilots.data(), h.ph_pilots.size(), hipMemcpyHostToDevice));
   }
-  (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr;
+  (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr;
   c->has_anchor = h.has_anchor; c->text_len = h.text_len; c->anchor_nw = h.anchor_nw;
   if (h.has_anchor) {
     // (the sparse table is the one large piece — 8 or 16 bytes x 8 levels per library base: if it does not fit next to the caller's
     //  buffers the index still works, through the kernels that do not need it)
     const bool got = hipMalloc((void**)&c->d_atable, h.atable.size() * sizeof(AEntry)) == hipSuccess && hipMalloc((void**)&c->d_text, h.text.size() * 4) == hipSuccess &&
-                     hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8) == hipSuccess;
+                     hipMalloc((void**)&c->d_akeys, h.akeys.size() * 4) == hipSuccess && hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8) == hipSuccess;
     if (!got) {
       (void)hipGetLastError();
-      (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr;
+      (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr;
       c->has_anchor = false;
     } else {
+      NB_HIP(hipMemcpy(c->d_akeys, h.akeys.data(), h.akeys.size() * 4, hipMemcpyHostToDevice));
       NB_HIP(hipMemcpy(c->d_atable, h.atable.data(), h.atable.size() * sizeof(AEntry), hipMemcpyHostToDevice));
       NB_HIP(hipMemcpy(c->d_text, h.text.data(), h.text.size() * 4, hipMemcpyHostToDevice));
       NB_HIP(hipMemcpy(c->d_sparse, h.sparse.data(), h.sparse.size() * 8, hipMemcpyHostToDevice));
@@ -1304,7 +1305,7 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   if (!c->d_ct) NB_HIP(hipMalloc((void**)&c->d_ct, sizeof(DevClasses)));
   NB_HIP(hipMemcpy(c->d_ct, &c->ct, sizeof(DevClasses), hipMemcpyHostToDevice));
   c->hash = h.hash; c->W = h.words_dev; c->W_ext = h.words; c->inv_perm = h.inv_perm; c->K = h.k; c->n_seqs = h.n_seqs;
-  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.text.size() * 4 + h.sparse.size() * 8); h.uploaded = 1;
+  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
 }
 
