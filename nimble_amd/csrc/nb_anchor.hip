@@ -49,6 +49,7 @@ struct AnchorHead {
   int pilot_lds_bytes, rec_dwords;                   // dynamic LDS: [pilots][per wave: rec_dwords x 64 dwords]
   long long text_words, sparse_words; int W;         // sizes, for the bounds-checked debug build (-DNB_ANCHOR_PROF -DNB_ANCHOR_CHECK)
   MateRes* mate_out;                                 // MATE kernels: one raw result per sequence instead of SPEC §4 / interning / outputs
+  int dbg;                                           // -DNB_ANCHOR_PROF only (NB_ANCHOR_DBG): 1 = sparse loads, 2 = table entries, 4 = text loads redirected to element 0 (WRONG results: cost attribution)
   uint32_t* scan_counts; long long scan_seg;         // scan list: workgroup b owns entries [b * scan_seg, ...) of ll.rc_list and counts them in
                                                      // scan_counts[b] (one LDS atomic per wave instead of one contended device atomic)
 };
@@ -127,6 +128,9 @@ __device__ __forceinline__ Look anchor_lookup(const AnchorHead& h, const uint8_t
   const uint32_t pilot = PLDS ? (uint32_t)s_pilots[gok ? pr.group : 0u] : ((valid && gok) ? (uint32_t)h.pilots[pr.group] : 0u);
   uint32_t slot = valid ? ph_slot(pr, pilot, h.ph) : 0u;
   if (!CHK(slot < h.ph.n_slots, 11)) slot = 0u;
+#ifdef NB_ANCHOR_PROF
+  if (h.dbg & 2) slot &= 1023u;
+#endif
   k.e = *reinterpret_cast<const uint4*>(&h.table[slot]);
   return k;
 }
@@ -250,6 +254,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
       const int lv = 31 - __builtin_clz(n);
       uint32_t off = n - (1u << lv);
       if (!CHK(n >= 1u && n < 256u && ((long long)lv * h.T + t + off + 1) * NW <= h.sparse_words, 13)) { t = 0u; off = 0u; }
+#ifdef NB_ANCHOR_PROF
+      if (h.dbg & 1) { t = 0u; off = 0u; }
+#endif
       const uint64_t* sp = h.sparse + ((size_t)(n >= 1u && n < 256u ? lv : 0) * (size_t)h.T + t) * NW;
       if (NW == 1) { v0 = sp[0] & sp[off]; v1 = 0ull; }
       else {
@@ -307,6 +314,9 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
           uint64_t sw; uint32_t sn; R.get32(run_q + K + steps, sw, sn);
           uint32_t tb = run_t + (uint32_t)(K + steps);
           if (!CHK((long long)(tb >> 4) + 3 <= h.text_words, 12)) tb = 0u;
+#ifdef NB_ANCHOR_PROF
+          if (h.dbg & 4) tb &= 4095u;
+#endif
           const U3 tw3 = *reinterpret_cast<const U3*>(h.text + (tb >> 4));
           const uint32_t sh = 2u * (tb & 15u);
           const uint64_t t01 = ((uint64_t)tw3.b << 32) | tw3.a;
@@ -776,7 +786,8 @@ static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads
   const int nwb = (max_len + 31) / 32, nwn = (nwb + 1) >> 1;
   return AnchorHead{c->d_atable, c->d_akeys, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
-                    (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out, c->d_scan_counts, 0};
+                    (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out,
+                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0};
 }
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {

@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
   LaneTail tail{ct, a, ll, W};
   std::vector<uint32_t> scan_counts((size_t)n_reads, 0);
   AnchorHead h{ix->atable.data(), ix->akeys.data(), ix->ph_pilots.data(), ix->ph, k, ix->text.data(), ix->sparse.data(), (long long)ix->text_len, reads.data(), lens.data(), max_len, stride, nwb,
-               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, scan_counts.data(), 64};
+               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64};
   const int positions = max_len - k + 1, nr = positions < 1 ? 1 : (positions + 63) / 64;
   const long long blocks = n_reads;
 #define RUN(NR) (ix->anchor_nw == 1 ? run_kernels<NR, 1>(h, &tail, blocks) : run_kernels<NR, 2>(h, &tail, blocks))
