@@ -279,9 +279,12 @@ class LibraryRun:
                 os.remove(self.part_path)
             return
         if self.world > 1:
+            import torch
             from . import merge
             rows, counts = self.ctx.classes()
-            rows, counts = merge.reduce_class_counts_hashed(rows, counts, device=cdev)
+            gpu = getattr(self.ctx, "device_id", None)                      # (the gloo tests drive this layer with a host stand-in for the ctx)
+            rows, counts = merge.reduce_class_counts_hashed(rows, counts, device=cdev,
+                                                            compute_device=torch.device("cuda", gpu) if gpu is not None and torch.cuda.is_available() else None)
             if self.rank != 0:
                 return
             feats = self.features_of_rows(rows)

@@ -75,11 +75,38 @@ def _all_gather_var(t, group, dev):
     return [o[:s] for o, s in zip(out, sizes)]
 
 
-def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0):
+def _lsr(h, n):
+    """logical right shift of an int64 tensor (torch's >> is arithmetic)"""
+    return (h >> n) & ((1 << (64 - n)) - 1)
+
+
+def row_digests_t(rows_t):
+    """[n, W] int64 tensor (bit patterns of the bitset rows) -> [n, 2] int64 on the same device: two independent 64-bit content hashes,
+    each the wrap-around SUM over the non-zero words of a mixed (word index, value): order-free, independent of trailing zero words,
+    one pass of elementwise kernels whatever W is (the chained digests of row_digests need W dependent steps)."""
+    import torch
+    n, W = rows_t.shape
+    k = torch.arange(1, W + 1, dtype=torch.int64, device=rows_t.device)
+    nz = (rows_t != 0).to(torch.int64)
+
+    def mix(h, c1, c2):
+        h = h ^ _lsr(h, 31); h = h * c1
+        h = h ^ _lsr(h, 27); h = h * c2
+        return h ^ _lsr(h, 33)
+    x1 = mix((rows_t ^ (k * -7046029254386353131)[None, :]) * -4417276706812531889, 0x7FB5D329728EA185, -9089946957438231219)
+    x2 = mix((rows_t + (k * 0x243F6A8885A308D3)[None, :]) * 0x13198A2E03707345, -49064778989728563, -4265267296055464877)
+    return torch.stack([(x1 * nz).sum(dim=1), (x2 * nz).sum(dim=1)], dim=1)
+
+
+def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, compute_device=None):
     """rows [n, W] uint64 / counts [n] int64 of THIS rank -> (global_rows, global_counts).
+    `device` is where the collective buffers live (the GPU under RCCL, the CPU under gloo), `compute_device` where the tensor ops run
+    (default: the same; a gloo rehearsal on a GPU box computes on the GPU and only moves the collective buffers through the host).
 
     Every rank gets global_counts (dense, in the agreed order = ascending 128-bit digest); global_rows is returned on the root only
-    (None elsewhere). One rank: identity (device id order)."""
+    (None elsewhere). One rank: identity (device id order). All the heavy steps run as tensor ops on `device` (the GPU under RCCL, the
+    CPU in the gloo tests): digests, one sort-based unique of the gathered digests, the dense count vector; rows travel point to point,
+    each distinct row once, and only from ranks other than the root."""
     import torch
     import torch.distributed as dist
     rows = np.ascontiguousarray(rows, dtype=np.uint64)
@@ -87,43 +114,57 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0):
     world, rank = _world(group)
     if world == 1:
         return rows, counts
-    dev = device if device is not None else torch.device("cpu")
-    W = rows.shape[1]
-    dig = row_digests(rows)
+    comm = device if device is not None else torch.device("cpu")
+    dev = compute_device if compute_device is not None else comm
+    n, W = rows.shape
+    rows_t = torch.from_numpy(rows.view(np.int64)).to(dev)
+    dig = row_digests_t(rows_t) if n else torch.zeros((0, 2), dtype=torch.int64, device=dev)
     # 1. dictionary agreement by digest: 16 bytes per class
-    parts = _all_gather_var(torch.from_numpy(dig.view(np.int64)), group, dev)
-    allv = torch.cat(parts, dim=0).cpu().numpy().view(np.uint64).reshape(-1, 2)
-    owner_of = np.concatenate([np.full(p.shape[0], r, dtype=np.int64) for r, p in enumerate(parts)])
-    order = np.lexsort((owner_of, allv[:, 1], allv[:, 0]))                 # digest order, lowest rank first inside a digest
-    srt = allv[order]
-    new = np.ones(srt.shape[0], dtype=bool)
-    new[1:] = (srt[1:] != srt[:-1]).any(axis=1)
-    gid_sorted = np.cumsum(new) - 1
-    gid = np.empty(srt.shape[0], dtype=np.int64)
-    gid[order] = gid_sorted
-    G = int(gid_sorted[-1]) + 1 if srt.shape[0] else 0
-    lo = sum(p.shape[0] for p in parts[:rank])
-    my_gid = gid[lo:lo + rows.shape[0]]
+    parts = _all_gather_var(dig.to(comm), group, comm)
+    sizes = [int(p.shape[0]) for p in parts]
+    allv = torch.cat(parts, dim=0).to(dev)
+    owner_of = torch.repeat_interleave(torch.arange(world, dtype=torch.int64, device=dev), torch.tensor(sizes, dtype=torch.int64, device=dev))
+    if allv.shape[0] == 0:
+        return (np.zeros((0, W), dtype=np.uint64) if rank == root else None), np.zeros(0, dtype=np.int64)
+    # unique over the first 64 bits (one radix sort), second 64 bits checked per group; a 64-bit tie between different rows (odds ~1e-8 for
+    # a million classes) falls back to the two-column unique
+    u1, inv = torch.unique(allv[:, 0], return_inverse=True)
+    first2 = torch.zeros(u1.shape[0], dtype=torch.int64, device=dev).scatter_(0, inv, allv[:, 1])
+    if bool((first2[inv] != allv[:, 1]).any()):
+        uniq, inv = torch.unique(allv, dim=0, return_inverse=True)
+    else:
+        uniq = torch.stack([u1, first2], dim=1)
+    G = int(uniq.shape[0])
+    lo = sum(sizes[:rank])
+    my_gid = inv[lo:lo + n]
     # 2. ONE all-reduce of the dense count vector
-    dense = torch.zeros(max(G, 1), dtype=torch.int64, device=dev)
-    if rows.shape[0]:
-        dense.index_add_(0, torch.from_numpy(my_gid).to(dev), torch.from_numpy(counts).to(dev))
-    dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
-    global_counts = dense.cpu().numpy()[:G]
-    # 3. rows to the root: each distinct row once, from its owner (the lowest rank that holds the digest)
-    first_pos = order[new]                                                  # position (in the concatenation) of each digest's owner copy
-    owner = owner_of[first_pos]
-    mine = first_pos[owner == rank] - lo                                    # my local class ids that I own
-    send = torch.from_numpy(rows[mine].view(np.int64).reshape(-1, W)) if W else torch.zeros((mine.shape[0], 0), dtype=torch.int64)
-    gathered = _gather_var_to_root(send, group, dev, root)
+    dense = torch.zeros(G, dtype=torch.int64, device=dev)
+    if n:
+        dense.index_add_(0, my_gid, torch.from_numpy(counts).to(dev))
+    dense_c = dense.to(comm)
+    dist.all_reduce(dense_c, op=dist.ReduceOp.SUM, group=group)
+    global_counts = dense_c.cpu().numpy()
+    # 3. rows to the root: each distinct row once, from its owner (the lowest rank that holds the digest); the root's own rows stay put
+    owner = torch.full((G,), world, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, owner_of, reduce="amin", include_self=True)
+    mine = owner[my_gid] == rank if n else torch.zeros(0, dtype=torch.bool, device=dev)
+    sel = torch.nonzero(mine).flatten()
+    sel = sel[torch.argsort(my_gid[sel])]                                   # in ascending global id: the order the root files them in
     global_rows = None
     if rank == root:
-        global_rows = np.zeros((G, W), dtype=np.uint64)
-        for r, block in enumerate(gathered):
-            ids = np.nonzero(owner == r)[0]
-            global_rows[ids] = block.cpu().numpy().view(np.uint64).reshape(-1, W)
-        if not (row_digests(global_rows) == srt[new]).all():               # every received row must hash to the digest it was filed under
+        g = torch.zeros((G, W), dtype=torch.int64, device=dev)
+        g[my_gid[sel]] = rows_t[sel]
+        per_owner = torch.bincount(owner, minlength=world + 1).cpu().tolist()
+        for r in range(world):
+            if r == root or per_owner[r] == 0:
+                continue
+            block = torch.empty((per_owner[r], W), dtype=torch.int64, device=comm)
+            dist.recv(block, src=r, group=group)
+            g[torch.nonzero(owner == r).flatten()] = block.to(dev)
+        if not bool((row_digests_t(g) == uniq).all()):                      # every row must hash to the digest it was filed under
             raise RuntimeError("class dictionary agreement: a received row does not match its digest")
+        global_rows = g.cpu().numpy().view(np.uint64).reshape(G, W)
+    elif sel.numel():
+        dist.send(rows_t[sel].contiguous().to(comm), dst=root, group=group)
     return global_rows, global_counts
 
 
