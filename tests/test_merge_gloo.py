@@ -139,9 +139,11 @@ def test_two_ranks_write_the_single_rank_files(built, tmp_path, gz):
     assert text[0].startswith("nimble_features\tnimble_score\tr1_CB\tr1_UB") and len(text) > 3000
 
 
-def test_reduce_by_digest_two_ranks_matches_exact_merge(built):
+@pytest.mark.parametrize("world,coarse", [(2, False), (3, False), (2, True)])
+def test_reduce_by_digest_matches_exact_merge(built, world, coarse):
     """reduce_class_counts_hashed against the dictionary merge of round 1 (distributed.merge_dictionaries) on overlapping tables,
-    incl. wide rows (157 words) where only 16 bytes per class are all-gathered."""
+    incl. wide rows (157 words) where only 16 bytes per class are all-gathered; two and three ranks (rows owned by every rank); `coarse`:
+    the first 64 bits of the digests made to tie on purpose (4 bits of them kept), which must send the agreement down its two-column path."""
     from nimble_amd import distributed
     rng = np.random.default_rng(5)
     W = 157
@@ -149,29 +151,38 @@ def test_reduce_by_digest_two_ranks_matches_exact_merge(built):
     for i in range(400):
         w = rng.integers(0, W - 2)
         pool[i, w:w + 3] = rng.integers(1, 2**63, 3, dtype=np.uint64)
-    a_ids, b_ids = rng.permutation(400)[:260], rng.permutation(400)[:250]
+    id_sets = [rng.permutation(400)[:260 - 10 * r] for r in range(world)]
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, q, pool, [a_ids, b_ids][r])) for r in range(2)]
+    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, q, pool, id_sets[r], coarse)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = dict(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     rows0, counts0 = res[0]
-    assert res[1][0] is None and (res[1][1] == counts0).all()              # rows on the root only, counts everywhere
+    for r in range(1, world):
+        assert res[r][0] is None and (res[r][1] == counts0).all()          # rows on the root only, counts everywhere
     want = {}
-    for ids in (a_ids, b_ids):
+    for ids in id_sets:
         for j, i in enumerate(ids):
             want[pool[i].tobytes()] = want.get(pool[i].tobytes(), 0) + int(j + 1)
     assert {r.tobytes(): int(c) for r, c in zip(rows0, counts0)} == want
-    assert len(want) == distributed.merge_dictionaries([pool[a_ids], pool[b_ids]]).shape[0]
+    assert len(want) == distributed.merge_dictionaries([pool[ids] for ids in id_sets]).shape[0]
 
 
-def _reduce_worker(rank, world, port, q, pool, ids):
+def _reduce_worker(rank, world, port, q, pool, ids, coarse=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if coarse:
+        real = merge.row_digests_t
+
+        def tied(rows_t):
+            d = real(rows_t).clone()
+            d[:, 0] &= 15
+            return d
+        merge.row_digests_t = tied
     rows, counts = merge.reduce_class_counts_hashed(pool[ids], np.arange(1, len(ids) + 1, dtype=np.int64))
     q.put((rank, (rows, counts)))
     dist.barrier()
