@@ -214,7 +214,7 @@ def main():
     if world > 1:
         # the end-of-job reduce runs once, inside the timed region: its first call in a process loads a dozen tensor-op kernels and opens
         # the point-to-point channels of the communicator (hundreds of ms, nothing to do with the job): do that here, on the warm-up's table
-        w_rows, w_counts = ctx.classes()
+        w_rows, w_counts = ctx.classes_device(stream)
         merge.reduce_class_counts_hashed(w_rows, w_counts, device=cdev, compute_device=dev)
         torch.cuda.synchronize()
 
@@ -229,9 +229,17 @@ def main():
         step()
         b.record(stream)
     torch.cuda.synchronize()
-    rows, counts = ctx.classes()
-    # end-of-job reduce (nimble_amd/merge.py): dictionary agreement by 16-byte digests, ONE all-reduce of the dense count vector, rows to rank 0
-    glob_rows, glob_counts = merge.reduce_class_counts_hashed(rows, counts, device=cdev, compute_device=dev)
+    # end-of-job reduce (nimble_amd/merge.py): dictionary agreement by 16-byte digests, ONE all-reduce of the dense count vector, rows to rank 0.
+    # Several ranks: the class table stays on the device until the merged rows reach the root (internal numbering, converted there).
+    if world > 1:
+        d_rows, d_counts = ctx.classes_device(stream)
+        glob_rows, glob_counts = merge.reduce_class_counts_hashed(d_rows, d_counts, device=cdev, compute_device=dev)
+        if rank == 0:
+            glob_rows = ctx.rows_to_external(glob_rows)
+        rows, counts = None, None
+    else:
+        rows, counts = ctx.classes()
+        glob_rows, glob_counts = rows, counts
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -247,6 +255,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    if rows is None:
+        rows, counts = ctx.classes()           # rank 0's own table, for the parity spot check below (outside the timed region)
     total_reads = n * world * args.steps
     value = total_reads / elapsed / 1e6
     bytes_per_read = (2 * L + 7) // 8 + (L + 7) // 8 + 8

@@ -151,6 +151,12 @@ int32_t nb_reasons_read(nb_ctx* ctx, int64_t* counts_out /* NB_NUM_REASONS */);
 int32_t nb_results_reset(nb_ctx* ctx, void* stream);
 /* device pointer + length of the per-class count vector (u64), for an RCCL reduce by the caller (bench.py, align.py) */
 int32_t nb_counts_device_ptr(nb_ctx* ctx, void** d_counts, int64_t* capacity);
+/* the class table for a caller that reduces it ON THE DEVICE (several ranks: nimble_amd/merge.py): copies rows [0, n) — in the engine's
+ * INTERNAL sequence numbering, words_internal u64 per row (nb_index_stats) — and their counts into the caller's device buffers, on `stream`;
+ * nb_rows_to_external turns such rows (host memory, e.g. the merged table on the root) into bitsets over the original sequence indices,
+ * words_per_row u64 per row. Internal numbering depends on the library alone: equal on every rank that built the same index. */
+int32_t nb_classes_copy_device(nb_ctx* ctx, int64_t n, uint64_t* d_rows_out, int64_t* d_counts_out, void* stream);
+int32_t nb_rows_to_external(nb_ctx* ctx, const uint64_t* rows_internal, int64_t n, uint64_t* rows_out);
 
 /* ---- FASTQ(.gz) ingest (host): replaces the Rust binary's decode of each "--input" file (__main__.py:177-179) and,
  * for 10x R1, the CB/UMI split of /root/reference/nimble/fastq_barcode_processor.py:131-141. Packs straight into the

@@ -281,10 +281,15 @@ class LibraryRun:
         if self.world > 1:
             import torch
             from . import merge
-            rows, counts = self.ctx.classes()
             gpu = getattr(self.ctx, "device_id", None)                      # (the gloo tests drive this layer with a host stand-in for the ctx)
-            rows, counts = merge.reduce_class_counts_hashed(rows, counts, device=cdev,
-                                                            compute_device=torch.device("cuda", gpu) if gpu is not None and torch.cuda.is_available() else None)
+            if gpu is not None and torch.cuda.is_available():               # the table stays on the device until the merged rows reach the root
+                rows, counts = self.ctx.classes_device()
+                rows, counts = merge.reduce_class_counts_hashed(rows, counts, device=cdev, compute_device=torch.device("cuda", gpu))
+                if self.rank == 0:
+                    rows = self.ctx.rows_to_external(rows)
+            else:
+                rows, counts = self.ctx.classes()
+                rows, counts = merge.reduce_class_counts_hashed(rows, counts, device=cdev)
             if self.rank != 0:
                 return
             feats = self.features_of_rows(rows)

@@ -1518,6 +1518,40 @@ static int read_rows_external(nb_ctx* c, int64_t first, int64_t count, uint64_t*
   return NB_OK;
 }
 
+static void renumber_rows(const nb_ctx* c, const uint64_t* in_rows, int64_t count, uint64_t* rows) {   // internal -> original numbering, up to 16 threads
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, std::min<int64_t>((int64_t)std::thread::hardware_concurrency(), count * (int64_t)c->W / (1 << 16))));
+  auto work = [&](int64_t lo, int64_t hi) {
+    std::memset(rows + (size_t)lo * (size_t)c->W_ext, 0, (size_t)(hi - lo) * (size_t)c->W_ext * 8);
+    for (int64_t r = lo; r < hi; ++r) {
+      const uint64_t* in = in_rows + (size_t)r * (size_t)c->W; uint64_t* out = rows + (size_t)r * (size_t)c->W_ext;
+      for (int w = 0; w < c->W; ++w) for (uint64_t v = in[w]; v; v &= v - 1) {
+          const int32_t o = c->inv_perm[(size_t)w * 64 + (size_t)__builtin_ctzll(v)];
+          if (o >= 0) out[o >> 6] |= 1ull << (o & 63);
+        }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work, count * t / T, count * (t + 1) / T);
+  work(0, count / T);
+  for (auto& x : th) x.join();
+}
+
+int32_t nb_classes_copy_device(nb_ctx* c, int64_t n, uint64_t* d_rows, int64_t* d_counts, void* stream) {
+  if (!c || n < 0) { set_error("nb_classes_copy_device: bad arguments"); return NB_ERR_INVALID; }
+  int64_t have = 0; const int rc = nb_classes_count(c, &have); if (rc != NB_OK) return rc;
+  if (n > have) { set_error("nb_classes_copy_device: more rows asked for than there are classes"); return NB_ERR_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  if (n && d_rows) NB_HIP(hipMemcpyAsync(d_rows, c->ct.rows, (size_t)n * (size_t)c->W * 8, hipMemcpyDeviceToDevice, s));
+  if (n && d_counts) NB_HIP(hipMemcpyAsync(d_counts, c->ct.counts, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+  return NB_OK;
+}
+
+int32_t nb_rows_to_external(nb_ctx* c, const uint64_t* rows_internal, int64_t n, uint64_t* rows_out) {
+  if (!c || n < 0 || (n && (!rows_internal || !rows_out)) || c->W <= 0) { set_error("nb_rows_to_external: bad arguments"); return NB_ERR_INVALID; }
+  if (n) renumber_rows(c, rows_internal, n, rows_out);
+  return NB_OK;
+}
+
 int32_t nb_classes_read(nb_ctx* c, int64_t cap, uint64_t* rows, int64_t* counts) {
   int64_t n = 0; const int rc = nb_classes_count(c, &n); if (rc != NB_OK) return rc;
   if (cap < n) { set_error("nb_classes_read: cap smaller than the number of classes"); return NB_ERR_INVALID; }

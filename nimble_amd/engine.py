@@ -184,6 +184,27 @@ class Context:
             check(_lib.lib().nb_classes_read(self._h, n.value, rows.ctypes.data_as(_lib.c_u64p), counts.ctypes.data_as(_lib.c_i64p)))
         return rows, counts
 
+    def classes_device(self, stream=None):
+        """(rows [n, words_internal] int64, counts [n] int64) as torch tensors on this GPU: the class table in the engine's INTERNAL
+        sequence numbering (equal on every rank that built the same index), copied device to device; rows_to_external() converts."""
+        import torch
+        n = self.n_classes()
+        w = self.index.stats()["words_internal"]
+        dev = torch.device("cuda", self.device_id)
+        rows = torch.empty((n, w), dtype=torch.int64, device=dev)
+        counts = torch.empty(n, dtype=torch.int64, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device_id)
+        check(_lib.lib().nb_classes_copy_device(self._h, n, ct.c_void_p(rows.data_ptr()), ct.c_void_p(counts.data_ptr()), ct.c_void_p(stream.cuda_stream)))
+        return rows, counts
+
+    def rows_to_external(self, rows_internal):
+        """[n, words_internal] uint64 (host) in internal numbering -> [n, words] uint64 bitsets over the original sequence indices."""
+        rows_internal = np.ascontiguousarray(rows_internal, dtype=np.uint64)
+        out = np.empty((rows_internal.shape[0], self.index.words), dtype=np.uint64)
+        check(_lib.lib().nb_rows_to_external(self._h, rows_internal.ctypes.data_as(_lib.c_u64p), rows_internal.shape[0], out.ctypes.data_as(_lib.c_u64p)))
+        return out
+
     def n_classes(self):
         n = ct.c_int64()
         check(_lib.lib().nb_classes_count(self._h, ct.byref(n)))

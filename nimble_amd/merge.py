@@ -109,15 +109,17 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
     each distinct row once, and only from ranks other than the root."""
     import torch
     import torch.distributed as dist
-    rows = np.ascontiguousarray(rows, dtype=np.uint64)
-    counts = np.ascontiguousarray(counts, dtype=np.int64)
     world, rank = _world(group)
+    on_device = isinstance(rows, torch.Tensor)        # (rows, counts) = Context.classes_device(): no host round trip before the collectives
+    if not on_device:
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
     if world == 1:
-        return rows, counts
+        return (rows.cpu().numpy().view(np.uint64), counts.cpu().numpy()) if on_device else (rows, counts)
     comm = device if device is not None else torch.device("cpu")
     dev = compute_device if compute_device is not None else comm
     n, W = rows.shape
-    rows_t = torch.from_numpy(rows.view(np.int64)).to(dev)
+    rows_t = rows.to(dev) if on_device else torch.from_numpy(rows.view(np.int64)).to(dev)
     dig = row_digests_t(rows_t) if n else torch.zeros((0, 2), dtype=torch.int64, device=dev)
     # 1. dictionary agreement by digest: 16 bytes per class
     parts = _all_gather_var(dig.to(comm), group, comm)
@@ -140,7 +142,7 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
     # 2. ONE all-reduce of the dense count vector
     dense = torch.zeros(G, dtype=torch.int64, device=dev)
     if n:
-        dense.index_add_(0, my_gid, torch.from_numpy(counts).to(dev))
+        dense.index_add_(0, my_gid, counts.to(dev) if on_device else torch.from_numpy(counts).to(dev))
     dense_c = dense.to(comm)
     dist.all_reduce(dense_c, op=dist.ReduceOp.SUM, group=group)
     global_counts = dense_c.cpu().numpy()
