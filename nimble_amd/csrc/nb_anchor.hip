@@ -732,6 +732,7 @@ static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_blo
   *plds = pil + 8 * rec <= budget;
   if (!*plds) pil = 0;
   int w = 12;                                  // (measured on c2: 8 / 10 / 12 waves 5.2 / 4.8 / 4.4 ms; 16 waves with a smaller first level 4.5 ms)
+  if (!*plds) w = 8;                           // no first level in LDS: two workgroups of 8 waves per CU (launch_anchor_t), 4 waves per SIMD
   if (const char* e = std::getenv("NB_ANCHOR_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 12) w = v; }
   while (w > 0 && pil + (int64_t)w * rec > budget) --w;
   if (w < 4) return 0;
@@ -743,6 +744,8 @@ template <int NR, int NW, bool PLDS, bool MATE>
 static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
   NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
+  if (!PLDS && waves <= 8) blocks *= 2;                              // first level in global memory (large libraries: fabric-bound): 16 waves per CU
+  if (const char* e = std::getenv("NB_ANCHOR_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) blocks = (long long)c->n_cu * v; }
   const long long need = (h_in.n + 64LL * waves - 1) / (64LL * waves);
   if (blocks > need) blocks = need;
   if (blocks < 1) blocks = 1;

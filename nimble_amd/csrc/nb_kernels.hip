@@ -1375,11 +1375,11 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     if (c->lists_cap < n) {
       (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;
       // [redo list: n][scan / reverse list: n + one batch per wave of slack: the anchor kernels give every workgroup its own segment of it]
-      c->scan_list_cap = n + (int64_t)c->n_cu * 12 * 64;
+      c->scan_list_cap = n + (int64_t)c->n_cu * 4 * 12 * 64;
       NB_HIP(hipMalloc((void**)&c->d_lists, (size_t)(n + c->scan_list_cap) * 4)); NB_HIP(hipMalloc((void**)&c->d_redo_lens, (size_t)n * 2)); NB_HIP(hipMalloc((void**)&c->d_redo_out, (size_t)n * 16));
       c->lists_cap = n;
     }
-    if (!c->d_scan_counts) { NB_HIP(hipMalloc((void**)&c->d_scan_counts, (size_t)c->n_cu * 4)); c->scan_counts_cap = c->n_cu; }
+    if (!c->d_scan_counts) { NB_HIP(hipMalloc((void**)&c->d_scan_counts, (size_t)c->n_cu * 4 * 4)); c->scan_counts_cap = (int64_t)c->n_cu * 4; }
     if (c->redo_words_cap < n * stride) {
       (void)hipFree(c->d_redo_reads); c->d_redo_reads = nullptr;
       NB_HIP(hipMalloc((void**)&c->d_redo_reads, (size_t)(n * stride) * 8)); c->redo_words_cap = n * stride;
@@ -1409,11 +1409,11 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
       max_len >= c->K && mate_max_len >= c->K && anchor_fits(c, max_len) && anchor_fits(c, mate_max_len)) {
     if (c->lists_cap < n) {
       (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;
-      c->scan_list_cap = n + (int64_t)c->n_cu * 12 * 64;
+      c->scan_list_cap = n + (int64_t)c->n_cu * 4 * 12 * 64;
       NB_HIP(hipMalloc((void**)&c->d_lists, (size_t)(n + c->scan_list_cap) * 4)); NB_HIP(hipMalloc((void**)&c->d_redo_lens, (size_t)n * 2)); NB_HIP(hipMalloc((void**)&c->d_redo_out, (size_t)n * 16));
       c->lists_cap = n; c->mate_res_cap = 0;                                   // (d_redo_mate_lens follows lists_cap)
     }
-    if (!c->d_scan_counts) { NB_HIP(hipMalloc((void**)&c->d_scan_counts, (size_t)c->n_cu * 4)); c->scan_counts_cap = c->n_cu; }
+    if (!c->d_scan_counts) { NB_HIP(hipMalloc((void**)&c->d_scan_counts, (size_t)c->n_cu * 4 * 4)); c->scan_counts_cap = (int64_t)c->n_cu * 4; }
     if (c->mate_res_cap < n) {
       (void)hipFree(c->d_mate_res); (void)hipFree(c->d_redo_mate_lens); c->d_mate_res = nullptr; c->d_redo_mate_lens = nullptr;
       NB_HIP(hipMalloc(&c->d_mate_res, (size_t)n * 2 * (size_t)anchor_mate_res_bytes())); NB_HIP(hipMalloc((void**)&c->d_redo_mate_lens, (size_t)c->lists_cap * 2));
