@@ -362,6 +362,7 @@ struct nb_ctx {
   uint32_t* d_akeys = nullptr;     // key words of d_atable alone (nb_internal.h, akeys)
   nb::AEntry* d_atable = nullptr; uint32_t* d_text = nullptr; uint64_t* d_sparse = nullptr; long long text_len = 0; bool has_anchor = false; int anchor_nw = 1;   // anchor structures (nb_anchor.hip)
   hipStream_t copy_stream = nullptr; hipStream_t last_stream = nullptr; bool last_stream_set = false;   // read-back stream; stream of the last nb_align_batch
+  bool h_stage_pinned = true;
   void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned host staging buffer of nb_classes_read (grown on demand, kept between calls)
   std::string last_kernels;        // kernels launched by the last nb_align_batch (nb_last_kernel_names)   // d_ct: device copy of ct (the single-end kernel reads it through a pointer)
   // score_percent table

@@ -1144,7 +1144,11 @@ int32_t nb_ctx_create(int32_t device_id, int64_t max_classes, nb_ctx** out) {
   // pinned allocation / first pageable copy of a process costs tens of milliseconds, which must not land in a caller's timed region
   NB_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   c->h_stage_cap = (size_t)32 << 20;
-  NB_HIP(hipHostMalloc(&c->h_stage, c->h_stage_cap, hipHostMallocDefault));
+  if (hipHostMalloc(&c->h_stage, c->h_stage_cap, hipHostMallocDefault) != hipSuccess) {   // (no pinned memory to be had: pageable staging, slower copies)
+    (void)hipGetLastError();
+    c->h_stage = std::malloc(c->h_stage_cap); c->h_stage_pinned = false;
+    if (!c->h_stage) { set_error("nb_ctx_create: out of host memory"); return NB_ERR_INVALID; }
+  }
   *out = c; return NB_OK;
 }
 
@@ -1152,7 +1156,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_scan_counts); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) (void)hipHostFree(c->h_stage); if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_scan_counts); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) { if (c->h_stage_pinned) (void)hipHostFree(c->h_stage); else std::free(c->h_stage); } if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_akeys); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
