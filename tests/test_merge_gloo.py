@@ -189,6 +189,25 @@ def _reduce_worker(rank, world, port, q, pool, ids, coarse=False):
     dist.destroy_process_group()
 
 
+def test_tensor_digest_ignores_padding_and_distinguishes_rows():
+    """row_digests_t (the digest the multi-rank reduce uses, tensor ops): distinct rows get distinct 128-bit digests, zero words beyond the
+    last non-zero one do not change them (ranks may hold rows of the same sets in tables of different width), and the two halves differ."""
+    import torch
+    rng = np.random.default_rng(2)
+    rows = rng.integers(0, 2**63, size=(3000, 12), dtype=np.uint64)
+    rows[rng.random((3000, 12)) < 0.8] = 0
+    rows[5] = rows[6]                                        # one genuine duplicate
+    t = torch.from_numpy(rows.view(np.int64))
+    d = merge.row_digests_t(t)
+    assert len({tuple(x) for x in d.tolist()}) == len({r.tobytes() for r in rows})
+    wide = torch.cat([t, torch.zeros((3000, 9), dtype=torch.int64)], dim=1)
+    assert bool((merge.row_digests_t(wide) == d).all())
+    swapped = t.clone(); swapped[:, [0, 1]] = swapped[:, [1, 0]]
+    moved = (t[:, 0] != t[:, 1])
+    assert bool((merge.row_digests_t(swapped)[moved] != d[moved]).any(dim=1).all())      # the word index is part of the hash
+    assert bool((d[:, 0] != d[:, 1]).any())
+
+
 def test_digest_ignores_padding_and_distinguishes_rows():
     rng = np.random.default_rng(0)
     rows = rng.integers(0, 2**63, size=(2000, 16), dtype=np.uint64)
