@@ -151,7 +151,7 @@ __device__ __forceinline__ LookKey anchor_lookup_key(const AnchorHead& h, const 
 }
 
 template <int NR, int NW, bool PLDS, bool MATE>
-__global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
+__global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   __shared__ unsigned int s_scan_n;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(768) void nb_anchor_kernel(AnchorHead h, const Lane
 // The reads none of whose three probes was in the table (ll.rc_list): every seed-scan position of BOTH orientations is looked up, all lanes
 // in lock-step, four lookups in flight per lane. No k-mer found at all: NO_HIT in both orientations, final. Anything found: redo list.
 template <int NR, bool PLDS, bool MATE>
-__global__ __launch_bounds__(768) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
+__global__ __launch_bounds__(1024) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_nohit;
   uint8_t* s_pilots = s_dyn;
@@ -722,8 +722,8 @@ __global__ __launch_bounds__(256) void nb_anchor_pair_kernel(const MateRes* __re
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
 
-// dynamic LDS of one workgroup: first level of the table (if it fits next to >= 8 waves of records: *plds) + record staging of up to 12
-// waves (the kernels need ~115 VGPRs; 16 waves bought nothing: the walk is bound by the SIMDs' issue rate, profiles/r02_tuning_notes.md)
+// dynamic LDS of one workgroup: first level of the table (if it fits next to >= 8 waves of records: *plds) + record staging of up to 16
+// waves (the kernels need ~110 VGPRs: 4 waves per SIMD)
 static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block, bool* plds) {
   const int nwb = (max_len + 31) / 32, nwn = (max_len + 63) / 64;
   const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4;
@@ -731,9 +731,10 @@ static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_blo
   const int64_t budget = (160 << 10) - 256;
   *plds = pil + 8 * rec <= budget;
   if (!*plds) pil = 0;
-  int w = 12;                                  // (measured on c2: 8 / 10 / 12 waves 5.2 / 4.8 / 4.4 ms; 16 waves with a smaller first level 4.5 ms)
+  int w = 16;                                  // (measured on c2, final kernels: 10 / 11 / 12 / 14 / 16 waves 4.43 / 4.10 / 3.80 / 3.77 / 3.41 ms: once the contended
+                                               //  atomics were gone and half the lookups read the small key array, the walk scales with the waves in flight)
   if (!*plds) w = 8;                           // no first level in LDS: two workgroups of 8 waves per CU (launch_anchor_t), 4 waves per SIMD
-  if (const char* e = std::getenv("NB_ANCHOR_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 12) w = v; }
+  if (const char* e = std::getenv("NB_ANCHOR_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) w = v; }
   while (w > 0 && pil + (int64_t)w * rec > budget) --w;
   if (w < 4) return 0;
   if (waves_per_block) *waves_per_block = w;

@@ -126,7 +126,7 @@ struct PHEntry { uint32_t key, pay; uint64_t m; };
 static_assert(sizeof(PHEntry) == 16, "perfect-hash entry must be 16 bytes");
 struct PHash { uint32_t a, c, n_slots, n_groups, hb, himask, stride; };
 constexpr uint32_t PH_PM = 0x9E3779u, PH_GM2 = 0xC2B2AE35u;   // PH_PM < 2^24: pilot * PH_PM is a full-rate 24-bit multiply
-constexpr int64_t PH_MAX_PILOT_BYTES = 96 << 10;        // first level must fit LDS next to the per-wave record staging (>= 8 waves per workgroup)
+constexpr int64_t PH_MAX_PILOT_BYTES = 84 << 10;        // first level must fit LDS next to the record staging of 16 waves of 150-bp reads (nb_anchor.hip: 4 waves per SIMD)
 constexpr int64_t PH_MAX_TABLE_BYTES = 16ll << 20;      // beyond that the second level leaves the L2s: the wave-per-read kernels take over
 struct PHProbe { uint32_t want, toff, group; };         // toff = t * stride
 NB_HD inline PHProbe ph_probe(uint64_t canon, const PHash& h) {
