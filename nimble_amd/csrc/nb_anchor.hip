@@ -730,6 +730,7 @@ static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_blo
   int64_t pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
   const int64_t budget = (160 << 10) - 256;
   *plds = pil + 8 * rec <= budget;
+  if (const char* e = std::getenv("NB_ANCHOR_PLDS")) { if (e[0] == '0') *plds = false; }     // (A/B: first level read from L2 although it would fit)
   if (!*plds) pil = 0;
   int w = 16;                                  // (measured on c2, final kernels: 10 / 11 / 12 / 14 / 16 waves 4.43 / 4.10 / 3.80 / 3.77 / 3.41 ms: once the contended
                                                //  atomics were gone and half the lookups read the small key array, the walk scales with the waves in flight)
