@@ -9,4 +9,4 @@ bash scripts/pmc_sq.sh ${TAG}_${CFG}_sq $READS $CFG > gpurun_out/${TAG}_${CFG}_s
 cp gpurun_out/${TAG}_${CFG}/bench.json gpurun_out/${TAG}_${CFG}_bench.json
 cp gpurun_out/${TAG}_${CFG}/summary.txt gpurun_out/${TAG}_${CFG}_summary.txt
 cp gpurun_out/${TAG}_${CFG}/traffic.json gpurun_out/${TAG}_${CFG}_traffic.json
-python scripts/merge_sq.py gpurun_out/${TAG}_${CFG}_traffic.json gpurun_out/${TAG}_${CFG}_sq.txt 3 | cut -c1-600
+python scripts/merge_sq.py gpurun_out/${TAG}_${CFG}_traffic.json gpurun_out/${TAG}_${CFG}_sq.txt ${WAVES_PER_SIMD:-4} | cut -c1-600
