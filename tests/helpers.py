@@ -188,12 +188,13 @@ def check_fullsize_properties(index, strs, cfg, d_reads, first_codes, L, max_cla
     return {"called_frac": float(a["reasons"][0]) / n, "sample_sets": sets}
 
 
-def weird_scenario(seed):
+def weird_scenario(seed, k=None):
     """A small library + reads built to be awkward for a kernel that follows the library text: homopolymers, short tandem repeats, palindromes
     (k-mers equal to their reverse complement), duplicated and nested sequences, Ns, sequences barely longer than k, reads that hop between
     sequences, reads made of a repeat unit. Returns (k, strs, reads, max_len)."""
     rng = np.random.default_rng(seed)
-    k = int(rng.choice([5, 8, 11, 15, 20, 23]))
+    k0 = int(rng.choice([5, 8, 11, 15, 20, 23]))
+    k = k0 if k is None else int(k)                                        # (k > 23: 16-byte table slots, keys with more than 32 bits above the slot hash)
     def rnd(n):
         return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
     comp = str.maketrans("ACGTN", "TGCAN")

@@ -104,12 +104,13 @@ def test_both_strands_and_repeats(built, emul, tmp_path):
     _run(emul, tmp_path, strs, 20, reads, 120, engine.make_config(), 0.60)                 # (many reads touch both-strand k-mers: redo list)
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_awkward_libraries(built, emul, tmp_path, seed):
-    """Homopolymers, tandem repeats, palindromes, duplicated / nested / reverse-complemented sequences, Ns, k from 5 to 23, reads that hop
-    between sequences (tests.helpers.weird_scenario): whatever the kernels finish themselves equals the oracle, under the sanitizers."""
+@pytest.mark.parametrize("seed,k_over", [(s, None) for s in range(12)] + [(100, 24), (101, 27), (102, 31), (103, 31)])
+def test_awkward_libraries(built, emul, tmp_path, seed, k_over):
+    """Homopolymers, tandem repeats, palindromes, duplicated / nested / reverse-complemented sequences, Ns, k from 5 to 23 (and 24, 27, 31:
+    16-byte table slots), reads that hop between sequences (tests.helpers.weird_scenario): whatever the kernels finish themselves equals the
+    oracle, under the sanitizers."""
     from tests.helpers import weird_scenario
-    k, strs, reads, max_len = weird_scenario(seed)
+    k, strs, reads, max_len = weird_scenario(seed, k_over)
     try:
         _run(emul, tmp_path, strs, k, reads, max_len, engine.make_config(k=k, score_threshold=k, score_filter=k + 2), 1.0)
     except AssertionError as e:

@@ -216,13 +216,13 @@ def test_fallback_kernels_stay_exact(built, monkeypatch, env, kernel):
     assert_same(gpu, ox.align(cfg, b1, o1, b2, o2, n_threads=8), f"pairs {env}")
 
 
-@pytest.mark.parametrize("seed", range(48))
-def test_awkward_libraries(built, seed):
+@pytest.mark.parametrize("seed,k_over", [(s, None) for s in range(48)] + [(100 + s, kk) for s in range(6) for kk in (24, 27, 31)])
+def test_awkward_libraries(built, seed, k_over):
     """The scenarios of tests/test_anchor_emul_cpu.py::test_awkward_libraries (and three times as many seeds) on the GPU, every read checked
     (the redo list included); every fourth scenario as paired templates (reads i and i + 80 as mates)."""
     from oracle import oracle
     from tests.helpers import weird_scenario
-    k, strs, reads, max_len = weird_scenario(seed)
+    k, strs, reads, max_len = weird_scenario(seed, k_over)               # k_over: k above 23 (wide table slots), same scenarios
     cfg = engine.make_config(k=k, score_threshold=k, score_filter=k + 2)
     words, lens = engine.pack_reads(reads, max_len)
     if seed % 4 == 3:
