@@ -364,6 +364,8 @@ def main():
                                       "16..64-B gathers FETCH_SIZE was calibrated against a known request count, profiles/r02_fetch_calibration.txt: it counts "
                                       "64 B per missing request, no x2 correction applies); algorithmic bytes per launch = " + str(bytes_per_read * n)) if traffic else None,
                      "kernel": ctx.last_kernels()[0], "kernels_per_step": ctx.last_kernels(), "kernel_ms_avg": avg_kernel_s * 1e3,
+                     "kernel_ms_note": "HIP events around one nb_align_batch call = every launch in kernels_per_step (the anchor kernel twice: all reads, then "
+                                       "the stragglers' retry list); compare with the per-step total of the nb:: kernels in the rocprofv3 summary",
                      "algorithmic_bytes_per_read": bytes_per_read},
         # The nearest memory-side ceiling: the rate at which the chip serves RANDOM 16-byte gathers (one cuckoo bucket = one dwordx4 = one
         # L1->L2 request) from a table of this size, MEASURED by the standalone microbenchmark scripts/gather_bench.hip

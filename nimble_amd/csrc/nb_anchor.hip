@@ -52,12 +52,18 @@ struct AnchorHead {
   int dbg;                                           // -DNB_ANCHOR_PROF only (NB_ANCHOR_DBG): 1 = sparse loads, 2 = table entries, 4 = text loads redirected to element 0 (WRONG results: cost attribution)
   uint32_t* scan_counts; long long scan_seg;         // scan list: workgroup b owns entries [b * scan_seg, ...) of ll.rc_list and counts them in
                                                      // scan_counts[b] (one LDS atomic per wave instead of one contended device atomic)
+  // Stragglers. A wave-batch lasts as long as its slowest lane (c2: 18 rounds for reads that need 7 on average). First pass (retry_out set):
+  // once no more than retry_lanes lanes are still walking, those reads are put on the workgroup's segment of the retry list (same segments as
+  // the scan list) and the wave moves on. Second pass (retry_in set, same grid): workgroup b maps its own segment, reads from scratch, in waves
+  // that hold nothing but long walks.
+  uint32_t* retry_out; const uint32_t* retry_in; uint32_t* retry_counts; int retry_lanes, retry_rounds;
 };
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
 
 #ifdef NB_ANCHOR_PROF   // phase clock for tuning (-DNB_ANCHOR_PROF through NB_EXTRA_HIPCC_FLAGS): cycles per phase summed over waves, see scripts/anchor_phases.py
 __device__ unsigned long long g_anchor_prof[16];
+__device__ unsigned long long g_anchor_hist[128];   // [0, 64): reads by the number of rounds their lane was busy; [64, 128): wave-batches by rounds
 #define PROF_MARK(slot) do { const long long t_ = clock64(); pacc[slot] += (unsigned long long)(t_ - tprof); tprof = t_; } while (0)
 #define PROF_COUNT(slot, v) do { pacc[slot] += (unsigned long long)(v); } while (0)
 #ifdef NB_ANCHOR_CHECK   // every computed index is compared with its array's size; a violation is counted (slots 10..15) and the access redirected to element 0
@@ -154,14 +160,15 @@ template <int NR, int NW, bool PLDS, bool MATE>
 __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
-  __shared__ unsigned int s_scan_n;
+  __shared__ unsigned int s_scan_n, s_retry_n;
   uint8_t* s_pilots = s_dyn;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wpb = (int)(blockDim.x >> 6);
   uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
+  const bool listed = h.retry_in != nullptr;     // second pass: this workgroup's segment of the retry list
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
-  if (threadIdx.x == 0) s_scan_n = 0;
+  if (threadIdx.x == 0) { s_scan_n = listed ? h.scan_counts[blockIdx.x] : 0u; s_retry_n = 0; }
   if (PLDS)
     for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
       *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
@@ -180,18 +187,24 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
   // the packed record of the NEXT batch is loaded into registers while this one is mapped (the reads stream from HBM exactly once)
   constexpr int MAXW = 3 * NR + 2;               // words of a record whose k-mer positions fit NR mask words (max_len <= 64 NR + 30)
   uint64_t nxt[MAXW];
+  const uint32_t* __restrict__ seg = listed ? h.retry_in + (size_t)blockIdx.x * (size_t)h.scan_seg : nullptr;
+  const long long cnt = listed ? (long long)h.retry_counts[blockIdx.x] : h.n;                       // reads of this pass / of this workgroup's segment
+  const long long first = listed ? (long long)wave * 64 : ((long long)blockIdx.x * wpb + wave) * 64;
+  const long long hop = listed ? (long long)wpb * 64 : nwaves * 64;
+  uint32_t nxt_r = 0;
   auto fetch = [&](long long b) {
     const long long i = b + lane;
-    const uint64_t* __restrict__ rp = h.reads + (size_t)(i < h.n ? i : 0) * h.stride;
+    nxt_r = i < cnt ? (listed ? seg[i] : (uint32_t)i) : 0u;
+    const uint64_t* __restrict__ rp = h.reads + (size_t)nxt_r * h.stride;
 #pragma unroll
-    for (int j = 0; j < MAXW; ++j) nxt[j] = (j < nwb + nwn && i < h.n) ? rp[j] : 0ull;
+    for (int j = 0; j < MAXW; ++j) nxt[j] = (j < nwb + nwn && i < cnt) ? rp[j] : 0ull;
   };
-  fetch(((long long)blockIdx.x * wpb + wave) * 64);
+  fetch(first);
 
-  for (long long base = ((long long)blockIdx.x * wpb + wave) * 64; base < h.n; base += nwaves * 64) {
+  for (long long base = first; base < cnt; base += hop) {
     const long long idx = base + lane;
-    const bool active = idx < h.n;
-    const uint32_t r = active ? (uint32_t)idx : 0u;
+    bool active = idx < cnt;
+    const uint32_t r = nxt_r;
     int L = 0;
     if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
     Rec R{rec + lane, 2 * nwb, 2 * nwn, L};
@@ -202,7 +215,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
 #pragma unroll
       for (int j = 0; j < MAXW; ++j) if (j < nwb + nwn) { R.at(2 * j) = (uint32_t)nxt[j]; R.at(2 * j + 1) = (uint32_t)(nxt[j] >> 32); }
       R.at(2 * (nwb + nwn)) = 0u; R.at(2 * (nwb + nwn) + 1) = 0u;
-      if (base + nwaves * 64 < h.n) fetch(base + nwaves * 64);
+      if (base + hop < cnt) fetch(base + hop);
     }
     const int last = L - K;
     bool rcf = false;                            // stream = reverse complement of the read
@@ -271,7 +284,20 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
     const int L5 = L / 5;
     int ls_q = 0, ls_room = 0; uint32_t ls_t = 0;   // first seed with a possible left extension: its position, anchor and left room
     int rounds = 0;
-    while (__ballot(mode != DONE)) {
+#ifdef NB_ANCHOR_PROF
+    int my_rounds = 0;
+#endif
+    bool to_retry = false;
+    uint64_t busy;
+    while ((busy = __ballot(mode != DONE)) != 0) {
+      if (h.retry_out && rounds >= h.retry_rounds && __popcll(busy) <= h.retry_lanes) {   // the few lanes left hold the whole wave: second pass
+        to_retry = mode != DONE;
+        if (to_retry) { mode = DONE; p_n = 0u; fl = 0u; active = false; }     // (nothing below touches this read: no outputs, no lists but the retry list)
+        break;
+      }
+#ifdef NB_ANCHOR_PROF
+      my_rounds += mode != DONE ? 1 : 0;
+#endif
       if (__ballot(mode == SEEK || mode == STEP)) {
         const bool act = mode == SEEK || mode == STEP;
         const bool step = mode == STEP;
@@ -390,6 +416,10 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
       if (solved) fl &= ~F_LEXT;
     }
     PROF_MARK(2); PROF_COUNT(8, rounds); PROF_COUNT(9, 1);
+#ifdef NB_ANCHOR_PROF
+    if (active) atomicAdd(&g_anchor_hist[my_rounds < 63 ? my_rounds : 63], 1ull);
+    if (lane == 0) atomicAdd(&g_anchor_hist[64 + (rounds < 63 ? rounds : 63)], 1ull);
+#endif
 
     // ---- the other orientation: does any of ITS seed-scan positions hit? (stream positions p = last, last - 3, ... not yet known) ----
     {
@@ -431,6 +461,15 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
     }
 
     PROF_MARK(3);
+    {
+      const uint64_t mr_ = __ballot(to_retry);
+      if (mr_) {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&s_retry_n, (uint32_t)__popcll(mr_));
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        if (to_retry) h.retry_out[(size_t)blockIdx.x * (size_t)h.scan_seg + b0 + (uint32_t)__popcll(mr_ & ((1ull << lane) - 1))] = r;
+      }
+    }
     if (MATE) {                                                               // paired path: the raw alignment of this mate, no decision here
       if (active) {
         uint32_t st = MATE_OK;
@@ -524,7 +563,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
   if (lane == 0) for (int i = 0; i < 16; ++i) if (pacc[i]) atomicAdd(&g_anchor_prof[i], pacc[i]);
 #endif
   __syncthreads();
-  if (threadIdx.x == 0) h.scan_counts[blockIdx.x] = s_scan_n;
+  if (threadIdx.x == 0) { h.scan_counts[blockIdx.x] = s_scan_n; if (h.retry_out) h.retry_counts[blockIdx.x] = s_retry_n; }
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
 
@@ -754,8 +793,31 @@ static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_
   AnchorHead h = h_in;                                               // scan-list segment of a workgroup: as many entries as it has reads
   h.scan_seg = ((h.n + blocks * waves * 64 - 1) / (blocks * waves * 64)) * waves * 64;
   if (blocks * h.scan_seg > c->scan_list_cap || blocks > c->scan_counts_cap) { set_error("launch_anchor: scan list too small"); return NB_ERR_INVALID; }
+  int retry_lanes = 6;                                               // (c2: 8.7 % of the reads walk for more than 12 rounds, waves for 18)
+  if (const char* e = std::getenv("NB_ANCHOR_RETRY_LANES")) { const int v = std::atoi(e); if (v >= 0 && v < 64) retry_lanes = v; }
+  long long retry_min = 64LL * 64 * waves;                           // (small batches: nothing to gain from a second launch)
+  if (const char* e = std::getenv("NB_ANCHOR_RETRY_MIN")) retry_min = std::atoll(e);
+  // (first level in global memory = a large library whose walk is bound by fabric requests, which a second walk of the stragglers only adds to:
+  //  c5 58.8 -> 60.9 ms with the pass; c2 3.37 -> 3.19 ms, paired templates 1 249 -> 1 343 M pairs/s, c3 unchanged)
+  c->anchor_retry_ran = PLDS && retry_lanes > 0 && h.n >= retry_min;
+  if (c->anchor_retry_ran) {
+    if (c->retry_cap < c->scan_list_cap || !c->d_retry_counts) {
+      (void)hipFree(c->d_retry_list); (void)hipFree(c->d_retry_counts); c->d_retry_list = nullptr; c->d_retry_counts = nullptr; c->retry_cap = 0;
+      NB_HIP(hipMalloc((void**)&c->d_retry_list, (size_t)c->scan_list_cap * 4)); NB_HIP(hipMalloc((void**)&c->d_retry_counts, (size_t)c->scan_counts_cap * 4));
+      c->retry_cap = c->scan_list_cap;
+    }
+    h.retry_out = c->d_retry_list; h.retry_in = nullptr; h.retry_counts = c->d_retry_counts; h.retry_lanes = retry_lanes;
+    h.retry_rounds = 10;                                             // (short reads — c3, 91 bp — finish in fewer rounds than that: nothing handed over, nothing lost)
+    if (const char* e = std::getenv("NB_ANCHOR_RETRY_ROUNDS")) h.retry_rounds = std::atoi(e);
+  }
   hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
   NB_HIP(hipGetLastError());
+  if (h.retry_out) {                                                 // second pass over the stragglers: same grid, workgroup b maps its own segment
+    h.retry_in = h.retry_out; h.retry_out = nullptr;
+    hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
+    NB_HIP(hipGetLastError());
+    h.retry_in = nullptr;
+  }
   NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (same grid: block b scans block b's segment)
   NB_HIP(hipGetLastError());
@@ -792,7 +854,7 @@ static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads
   return AnchorHead{c->d_atable, c->d_akeys, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
                     (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out,
-                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0};
+                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0};
 }
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
@@ -843,5 +905,10 @@ extern "C" int nb_debug_anchor_prof(unsigned long long* out16) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(nb::g_anchor_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
   unsigned long long z[16] = {0};
   return hipMemcpyToSymbol(HIP_SYMBOL(nb::g_anchor_prof), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+extern "C" int nb_debug_anchor_hist(unsigned long long* out128) {
+  if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(nb::g_anchor_hist), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+  unsigned long long z[128] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(nb::g_anchor_hist), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif

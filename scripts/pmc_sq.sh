@@ -18,7 +18,7 @@ for f in sorted(glob.glob(os.path.join(out,'sq*','**','*counter_collection.csv')
         if 'nb::' in r['Kernel_Name']:
             agg.setdefault(r['Counter_Name'],[]).append(float(r['Counter_Value']))
             per.setdefault((r['Kernel_Name'][:44], r['Counter_Name']),[]).append(float(r['Counter_Value']))
-    steps=max(len(v) for v in per.values())
+    steps=min(len(v) for v in per.values())          # (the anchor kernel is launched twice per step, gather and scatter once)
     for k,v in agg.items(): print(f"{k}: {sum(v)/steps:.4g}")          # per step: summed over the kernels of one nb_align_batch call
     for (kn,c),v in sorted(per.items()): print(f"  {kn:44s} {c}: {sum(v)/len(v):.4g}")
 PY

@@ -34,19 +34,31 @@ def main(out, cfg="c2"):
         print(",".join(cols))
         for r in rows[:12]:
             print(",".join(str(r.get(c, ""))[:110] for c in cols))
+        # one step of the bench = one nb_align_batch call = several nb:: launches (the anchor kernel twice: all reads, then the stragglers'
+        # retry list): bench.py's kernel_ms_avg is their sum per step, to be compared with the total printed here
+        nb = [r for r in rows if "nb::" in r.get("Name", "")]
+        if nb:
+            calls = min(int(r["Calls"]) for r in nb)
+            print(f"# nb:: kernels, per step (steps incl. warm-up = {calls}, the launch count of the kernels that run once per step):")
+            tot = 0.0
+            for r in nb:
+                per = float(r["TotalDurationNs"]) / calls / 1e6
+                tot += per
+                print(f"#   {r['Name'][:80]}: {int(r['Calls']) / calls:g} launches, {per:.3f} ms")
+            print(f"#   all nb:: kernels: {tot:.3f} ms per step")
     for tag in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_l1"):
         for f in find(os.path.join(out, tag), "*counter_collection.csv"):
             print(f"\n## {tag} ({os.path.relpath(f, out)}) — per-dispatch counter values of the alignment kernel")
             # one step of the bench = every nb:: kernel of one nb_align_batch call (lane-per-read path: forward pass, reverse
             # worklist, gather, wave-per-read kernel over the redo list, scatter): per-step value = sum over those kernels / steps,
-            # steps = dispatches of the kernel that ran most often among the dominant ones
+            # steps = dispatches of a kernel that runs once per step
             agg, total = {}, {}
             for r in csv.DictReader(open(f)):
                 if "nb::" not in r.get("Kernel_Name", ""):
                     continue
                 key = (r["Kernel_Name"][:60], r["Counter_Name"])
                 agg.setdefault(key, []).append(float(r["Counter_Value"]))
-            steps = max((len(v) for v in agg.values()), default=1)
+            steps = min((len(v) for v in agg.values()), default=1)      # (the anchor kernel is launched twice per step, gather / scatter once)
             for (k, c), v in agg.items():
                 print(f"{k} {c}: dispatches={len(v)} mean={sum(v) / len(v):.1f} min={min(v):.1f} max={max(v):.1f}")
                 total[c] = total.get(c, 0.0) + sum(v)

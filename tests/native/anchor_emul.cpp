@@ -14,6 +14,7 @@
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -30,14 +31,27 @@ using namespace nb;
 
 template <class T> static T rd(FILE* f) { T v; if (std::fread(&v, sizeof v, 1, f) != 1) { std::fprintf(stderr, "short input\n"); std::exit(2); } return v; }
 
+static unsigned long long g_retried = 0;
 template <int NR, int NW>
-static void run_kernels(const AnchorHead& h, const LaneTail* tail, long long blocks) {
-  // one wave per workgroup, one lane per wave: block b maps read 64 * b, then (second pass) scans its own segment of the scan list
+static void run_kernels(const AnchorHead& h_in, const LaneTail* tail, long long blocks, std::vector<uint32_t>* retry) {
+  // one wave per workgroup, one lane per wave: block b maps read 64 * b, then (last pass) scans its own segment of the scan list.
+  // retry: every other read is handed to the second pass of nb_anchor_kernel after its first round (retry_lanes = 1 with one lane per wave,
+  // switched per block), which maps its segment of the retry list from scratch.
   blockDim = dim3(64); gridDim = dim3((unsigned)blocks); threadIdx = dim3(0);
-  for (int pass = 0; pass < 2; ++pass)
+  AnchorHead h = h_in;
+  std::vector<uint32_t> counts((size_t)blocks, 0);
+  for (int pass = 0; pass < 3; ++pass)
     for (long long b = 0; b < blocks; ++b) {
       blockIdx = dim3((unsigned)b);
-      if (pass == 0) nb_anchor_kernel<NR, NW, false, false>(h, tail); else nb_anchor_scan_kernel<NR, false, false>(h, tail);
+      if (pass == 0) {
+        h.retry_in = nullptr; h.retry_out = (retry && (b & 1)) ? retry->data() : nullptr; h.retry_counts = counts.data(); h.retry_lanes = 1;
+        nb_anchor_kernel<NR, NW, false, false>(h, tail);
+        if (h.retry_out) g_retried += counts[(size_t)b];
+      } else if (pass == 1) {
+        if (!retry) continue;
+        h.retry_out = nullptr; h.retry_in = retry->data(); h.retry_counts = counts.data();
+        nb_anchor_kernel<NR, NW, false, false>(h, tail);
+      } else { h.retry_in = nullptr; h.retry_out = nullptr; nb_anchor_scan_kernel<NR, false, false>(h, tail); }
     }
 }
 
@@ -83,10 +97,12 @@ int main(int argc, char** argv) {
   LaneTail tail{ct, a, ll, W};
   std::vector<uint32_t> scan_counts((size_t)n_reads, 0);
   AnchorHead h{ix->atable.data(), ix->akeys.data(), ix->ph_pilots.data(), ix->ph, k, ix->text.data(), ix->sparse.data(), (long long)ix->text_len, reads.data(), lens.data(), max_len, stride, nwb,
-               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64};
+               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0};
+  std::vector<uint32_t> retry_list((size_t)n_reads * 64 + 64, 0);
+  std::vector<uint32_t>* retry = std::getenv("NB_EMUL_RETRY") ? &retry_list : nullptr;
   const int positions = max_len - k + 1, nr = positions < 1 ? 1 : (positions + 63) / 64;
   const long long blocks = n_reads;
-#define RUN(NR) (ix->anchor_nw == 1 ? run_kernels<NR, 1>(h, &tail, blocks) : run_kernels<NR, 2>(h, &tail, blocks))
+#define RUN(NR) (ix->anchor_nw == 1 ? run_kernels<NR, 1>(h, &tail, blocks, retry) : run_kernels<NR, 2>(h, &tail, blocks, retry))
   switch (nr) { case 1: RUN(1); break; case 2: RUN(2); break; case 3: RUN(3); break; case 4: RUN(4); break; default: RUN(5); break; }
   if (err) { std::fprintf(stderr, "class table error %u\n", err); return 5; }
 
@@ -115,7 +131,7 @@ int main(int argc, char** argv) {
   }
   std::fclose(o);
   uint32_t n_scan = 0; for (uint32_t v : scan_counts) n_scan += v;
-  std::printf("reads %d, scan list %u, redo list %u, classes %u\n", n_reads, n_scan, counters[1], n_classes);
+  std::printf("reads %d, scan list %u, redo list %u, retried %llu, classes %u\n", n_reads, n_scan, counters[1], g_retried, n_classes);
   delete ix;
   return 0;
 }

@@ -216,6 +216,34 @@ def test_fallback_kernels_stay_exact(built, monkeypatch, env, kernel):
     assert_same(gpu, ox.align(cfg, b1, o1, b2, o2, n_threads=8), f"pairs {env}")
 
 
+@pytest.mark.parametrize("lanes,rounds", [(0, 0), (6, 10), (8, 4), (24, 2), (63, 0)])
+def test_straggler_retry_pass(built, monkeypatch, lanes, rounds):
+    """nb_anchor_kernel hands the reads still walking after NB_ANCHOR_RETRY_ROUNDS rounds, when at most NB_ANCHOR_RETRY_LANES lanes of the wave
+    are busy, to a second pass over the workgroup's retry-list segment. Small batches skip that pass unless NB_ANCHOR_RETRY_MIN says otherwise:
+    force it here, from 'never' (0 lanes) to 'every walking read, before its first round' (63 lanes, 0 rounds), single-end (ragged lengths,
+    Ns) and paired, against the oracle."""
+    from oracle import oracle
+    from tests.test_general_gpu import synth_pairs
+    monkeypatch.setenv("NB_ANCHOR_RETRY_MIN", "0"); monkeypatch.setenv("NB_ANCHOR_RETRY_LANES", str(lanes)); monkeypatch.setenv("NB_ANCHOR_RETRY_ROUNDS", str(rounds))
+    _, seqs, strs, _ = library_strings(20, 50)
+    codes = synth.synth_reads(seqs, 30000, 150, seed=33, err=0.02, n_rate=0.003)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 151, codes.shape[0]).astype(np.uint16); lens[::3] = 150
+    cfg = engine.make_config()
+    index = engine.Index(strs, 20)
+    gpu = run_gpu(index, cfg, synth.pack_codes(codes), lens, 150)
+    assert gpu["kernels"][0].startswith("nb_anchor_kernel"), gpu["kernels"]
+    assert (gpu["kernels"][1] == gpu["kernels"][0]) == (lanes > 0), gpu["kernels"]          # the second launch is reported
+    reads = ["".join("ACGTN"[c] for c in row[:L]) for row, L in zip(codes, lens)]
+    ox = oracle.OracleIndex(strs, 20)
+    assert_same(gpu, ox.align_strs(cfg, reads, n_threads=8), f"single-end, retry lanes {lanes} rounds {rounds}")
+    c1, c2 = synth_pairs(seqs, 6000, 100, 91, seed=9)
+    gpu = run_gpu(index, cfg, synth.pack_codes(c1), None, 100, mate_words=synth.pack_codes(c2), mate_max_len=91)
+    assert gpu["kernels"][0].startswith("nb_anchor_kernel<mates>"), gpu["kernels"]
+    b1, o1 = synth.reads_to_ascii(c1); b2, o2 = synth.reads_to_ascii(c2)
+    assert_same(gpu, ox.align(cfg, b1, o1, b2, o2, n_threads=8), f"pairs, retry lanes {lanes} rounds {rounds}")
+
+
 @pytest.mark.parametrize("seed,k_over", [(s, None) for s in range(48)] + [(100 + s, kk) for s in range(6) for kk in (24, 27, 31)])
 def test_awkward_libraries(built, seed, k_over):
     """The scenarios of tests/test_anchor_emul_cpu.py::test_awkward_libraries (and three times as many seeds) on the GPU, every read checked
