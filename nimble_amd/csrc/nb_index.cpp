@@ -270,7 +270,9 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     bool done = false;
     // (a canonical k-mer present on BOTH strands needs two of the four slots of its bucket pair: a library that holds sequences and their
     //  reverse complements only fills to about half the usual load, hence the long tail of attempts)
-    for (int attempt = 0; attempt < 40 && !done; ++attempt, load *= (attempt % 2 == 0 ? 0.92 : 1.0)) {
+    const char* att_env = std::getenv("NB_COMPACT_ATTEMPTS");           // (tests: 0 = "placement failed", the wide table takes over)
+    const int max_attempts = att_env ? std::atoi(att_env) : 40;
+    for (int attempt = 0; attempt < max_attempts && !done; ++attempt, load *= (attempt % 2 == 0 ? 0.92 : 1.0)) {
       CHash h{}; h.a = MULS[attempt % 4][0]; h.c = MULS[attempt % 4][1]; h.hb = hb; h.himask = hb ? ((1u << hb) - 1u) : 0u;
       uint64_t nb64 = std::max<uint64_t>(nb_min, (uint64_t)((double)n_entries / (2.0 * load)) + 1);
       if (nb64 > 0x7FFFFFFFull) break;
@@ -302,15 +304,19 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
           const uint32_t key = p.want | (uint32_t)s;
           if (key == CKEY_EMPTY || (key | 2u) == CKEY_EMPTY) { ok = false; break; }   // would read as an empty entry: other multipliers
           ok = place(key, c.pay[s], p.b1);
+          if (!ok && std::getenv("NB_INDEX_DEBUG")) std::fprintf(stderr, "[index]   placement failed for canon %llx strand %d b1 %u b2 %u want %08x pay %08x\n", (unsigned long long)c.key, s, p.b1, p.b2, p.want, c.pay[s]);
         }
         if (!ok) break;
       }
+      if (!ok && std::getenv("NB_INDEX_DEBUG")) std::fprintf(stderr, "[index] compact table attempt %d failed: %lld entries, %llu buckets, load %.3f\n", attempt, (long long)n_entries, (unsigned long long)nb64, load);
       if (ok) { ix->compact = true; ix->chash = h; ix->ctable.swap(tab); done = true; }
     }
-    if (!done) { delete ix; set_error("nb_index_build: could not place the k-mers in the compact table"); return NB_ERR_UNSUPPORTED; }
+    // (no placement after all attempts — e.g. k = 23 with a small library, where the table stays at its minimum size and a bucket index is
+    //  almost all "high bits of the k-mer": allelic variants of one k-mer pile into the same two buckets — is no error: the wide table below
+    //  holds any library)
     ix->hash = KmerHash{0, 0, 0};
-
-  } else {
+  }
+  if (!ix->compact) {
   uint64_t nb64 = (uint64_t)((double)n_canon / (SLOTS_PER_BUCKET * TABLE_MAX_LOAD)) + 1;
   if (nb64 < 256) nb64 = 256;
   if (nb64 > 0x7FFFFFFFull) { delete ix; set_error("nb_index_build: k-mer table would exceed 2^31 buckets"); return NB_ERR_UNSUPPORTED; }

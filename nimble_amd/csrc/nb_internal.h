@@ -96,7 +96,10 @@ NB_HD inline uint32_t nb_brev32(uint32_t x) {
   return (x >> 16) | (x << 16);
 #endif
 }
-NB_HD inline uint32_t compact_alt_delta(uint32_t want, const CHash& h) { return 1u + nb_mulhi32(nb_brev32(want) << 2, h.nbm1); }   // in [1, nb - 1]; want = rem << 2
+// in [1, nb - 1]; want = rem << 2. The fold brings every bit of rem into the 17 low bits that the reversal moves to the top: the reversal
+// alone looked at the LOW bits of rem only, which k-mers that differ in one high base (allelic variants: the multiply of compact_probe
+// carries upward only) share — and with them home AND alternate bucket (a library of 150 sequences at k = 23 could not be placed).
+NB_HD inline uint32_t compact_alt_delta(uint32_t want, const CHash& h) { return 1u + nb_mulhi32(nb_brev32(want ^ (want >> 15)), h.nbm1); }
 NB_HD inline CProbe compact_probe(uint64_t canon, const CHash& h) {
   const uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
   const uint32_t m = (lo * h.a) ^ (hi * h.c);

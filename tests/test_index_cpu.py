@@ -29,6 +29,27 @@ def test_index_matches_oracle(built, k, n_loci, alleles, locus_len):
             assert ix.query(p) == ox.query(p), p
 
 
+@pytest.mark.parametrize("attempts", [None, "0"])
+def test_allelic_variants_at_k23_and_compact_placement_failure(built, monkeypatch, attempts):
+    """Found by scripts/fuzz_gpu.py (seed 1315): 3 loci x 50 alleles of 600 bases at k = 23. The compact table stays at its minimum
+    size there, a bucket index is almost all 'high bits of the k-mer', and allelic variants of one k-mer used to share home AND alternate
+    bucket: no placement, and nb_index_build failed. Now the alternate bucket mixes every bit of the remainder, and a placement that
+    fails anyway (forced here with NB_COMPACT_ATTEMPTS=0) falls back to the wide table instead of an error."""
+    from oracle import oracle
+    if attempts is not None:
+        monkeypatch.setenv("NB_COMPACT_ATTEMPTS", attempts)
+    _, _, strs, _ = library_strings(3, 50, locus_len=600, seed=1315)
+    ix, ox = engine.Index(strs, 23), oracle.OracleIndex(strs, 23)
+    st = ix.stats()
+    assert st["compact"] == (1 if attempts is None else 0) and st["n_kmers"] == ox.num_kmers and st["anchor_bytes"] > 0
+    rng = np.random.default_rng(3)
+    comp = str.maketrans("ACGT", "TGCA")
+    probes = [s[i:i + 23] for s in strs[::7] for i in range(0, len(s) - 22, 5)]
+    probes += [p.translate(comp)[::-1] for p in probes[::3]] + ["".join("ACGT"[c] for c in rng.integers(0, 4, 23)) for _ in range(300)]
+    for p in probes:
+        assert ix.query(p) == ox.query(p), p
+
+
 def test_colour_ids_ascend_by_size(built):
     """The kernels seed the intersection with min(colour id): ids must be ordered by class size."""
     _, _, strs, _ = library_strings(3, 7, 300, seed=5)
