@@ -22,16 +22,23 @@ done = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     loci, alleles = int(rng.choice([1, 3, 8, 20, 40])), int(rng.choice([2, 10, 50, 70]))
-    L = int(rng.choice([40, 64, 91, 150, 151, 250]))
+    L = int(rng.choice([40, 64, 91, 150, 151, 250, 339]))
     locus_len = int(rng.choice([max(L + 20, 300), 600, 1098]))
-    k = int(rng.choice([20, 20, 20, 16, 23, 12]))
+    k = int(rng.choice([20, 20, 20, 16, 23, 12, 22, 27, 31, 9]))
+    if rng.random() < 0.08:
+        loci, alleles = int(rng.choice([60, 100])), 70                    # classes of two words, thousands of sequences
     _, seqs, strs, _ = library_strings(loci, alleles, locus_len=locus_len, seed=seed)
     err, n_rate, frac_random = float(rng.choice([0.0, 0.004, 0.01, 0.03])), float(rng.choice([0.0, 0.001, 0.01])), float(rng.choice([0.02, 0.1, 0.6]))
     kw = [dict(), dict(discard_multiple_matches=True), dict(strand_filter="fiveprime"), dict(score_percent=0.8, score_threshold=30), dict(strand_filter="threeprime", score_filter=40)][int(rng.integers(0, 5))]
+    if rng.random() < 0.15:
+        kw = dict(kw, num_mismatches=int(rng.integers(1, 3)))              # tolerated mismatches: the general kernel
+    if "score_threshold" not in kw:
+        kw = dict(kw, score_threshold=max(k, 20), score_filter=max(k + 5, kw.get("score_filter", 25)))
     cfg = engine.make_config(k=k, **kw)
     index = engine.Index(strs, k)
     ox = oracle.OracleIndex(strs, k)
     paired = rng.random() < 0.3
+    L = min(L, 320 + k - 1, 250 if paired else 339)                        # NB_MAX_POSITIONS; fragments of synth_pairs are 300 bases
     t0 = time.time()
     if paired:
         n = 60_000
