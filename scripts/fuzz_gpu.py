@@ -14,12 +14,10 @@ from oracle import oracle  # noqa: E402
 from tests.helpers import assert_same, library_strings, run_gpu  # noqa: E402
 from tests.test_general_gpu import synth_pairs  # noqa: E402
 
-os.environ.setdefault("NB_ANCHOR_RETRY_MIN", "20000")          # (pairs come in batches of 60 k: run the stragglers' pass there too)
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-t_end = time.time() + budget
-done = 0
-while time.time() < t_end:
+
+
+def scenario(seed):
+    """One random scenario, GPU against the oracle (AssertionError on the first difference); returns its one-line description."""
     rng = np.random.default_rng(seed)
     loci, alleles = int(rng.choice([1, 3, 8, 20, 40])), int(rng.choice([2, 10, 50, 70]))
     L = int(rng.choice([40, 64, 91, 150, 151, 250, 339]))
@@ -64,7 +62,18 @@ while time.time() < t_end:
             ora = ox.align_strs(cfg, ["".join("ACGTN"[c] for c in row[:ln]) for row, ln in zip(codes, lens)], n_threads=16)
         what = f"seed {seed}: {n} x {L} bp{' ragged' if lens is not None else ''}, {loci}x{alleles} seqs of {locus_len}, k={k}, err {err} N {n_rate} foreign {frac_random}, {kw}"
     assert_same(gpu, ora, what)
-    done += 1
-    print(f"ok {what}; called {float((ora['reason'] == 0).mean()):.3f}; kernels {[x.split('<')[0] for x in gpu['kernels']]}; {time.time() - t0:.1f} s", flush=True)
-    seed += 1
-print(f"{done} scenarios identical to the oracle")
+    return (f"ok {what}; called {float((ora['reason'] == 0).mean()):.3f}; kernels {[x.split('<')[0] for x in gpu['kernels']]}; {time.time() - t0:.1f} s")
+
+
+
+if __name__ == "__main__":
+    os.environ.setdefault("NB_ANCHOR_RETRY_MIN", "20000")          # (pairs come in batches of 60 k: run the stragglers' pass there too)
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t_end = time.time() + budget
+    done = 0
+    while time.time() < t_end:
+        print(scenario(seed), flush=True)
+        done += 1
+        seed += 1
+    print(f"{done} scenarios identical to the oracle")
