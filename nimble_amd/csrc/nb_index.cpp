@@ -360,14 +360,16 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     // table higher: a group of s k-mers finds a free pilot among 256 only while (1 - fill)^s stays above a few per cent)
     int64_t G = std::max<int64_t>(1, std::min<int64_t>(pilot_cap, (int64_t)((double)n / 2.5)));
     int64_t table_cap = PH_MAX_TABLE_BYTES;
-    if ((double)n / (double)G > 16.0 || ix->max_desc_nw != 1) {         // too many k-mers for an LDS first level (or classes the lane kernel cannot hold):
-      G = std::max<int64_t>(1, (int64_t)((double)n / 3.0));              // first level in global memory, one pilot per 3 k-mers
-      table_cap = PH_LARGE_MAX_TABLE_BYTES;
-    }
+    // too many k-mers for an LDS first level (or classes the lane kernel cannot hold): first level in global memory, one pilot per 3 k-mers.
+    // Also the second try when the LDS-sized first level finds no pilots: groups of 7+ k-mers (libraries of ~2 000 .. 4 000 sequences) do not
+    // place with one-byte pilots at any useful load — such a library used to end up without perfect hash, i.e. on the wave-per-read kernels.
+    const bool large_first = (double)n / (double)G > 16.0 || ix->max_desc_nw != 1;
+    for (int variant = large_first ? 1 : 0; variant < 2 && !ix->has_ph; ++variant) {
+    if (variant == 1) { G = std::max<int64_t>(1, (int64_t)((double)n / 3.0)); table_cap = PH_LARGE_MAX_TABLE_BYTES; }
     const double lambda = (double)n / (double)G;
     // (groups of ~3 k-mers with one-byte pilots fill to ~0.84: start there instead of walking down from 0.95, every failed attempt is a
-    //  full pass over the k-mers)
-    for (double alpha = table_cap == PH_MAX_TABLE_BYTES ? 0.95 : 0.84; alpha >= 0.55 && !ix->has_ph; alpha -= 0.02) {
+    //  full pass over the k-mers; groups of 6+ never fill beyond ~0.75)
+    for (double alpha = table_cap == PH_MAX_TABLE_BYTES ? (lambda > 6.0 ? 0.75 : 0.95) : 0.84; alpha >= 0.55 && !ix->has_ph; alpha -= 0.02) {
       const uint64_t N = std::max<uint64_t>({(uint64_t)((double)n / alpha) + 1, nb_min, 1024});
       if (dbg) std::fprintf(stderr, "[nb_index] perfect hash: alpha=%.2f N=%llu G=%lld lambda=%.2f\n", alpha, (unsigned long long)N, (long long)G, lambda);
       if ((int64_t)N * 16 > table_cap || N > 0x7FFFFFFFull || lambda > 16.0) break;
@@ -421,6 +423,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       }
       if (bad_key) { if (dbg) std::fprintf(stderr, "[nb_index]   key / word index out of range\n"); break; }
       ix->has_ph = true; ix->ph = h; ix->ph_table.swap(tab); ix->ph_pilots.swap(pilots);
+    }
     }
 
     lap("perfect hash");

@@ -50,6 +50,24 @@ def test_allelic_variants_at_k23_and_compact_placement_failure(built, monkeypatc
         assert ix.query(p) == ox.query(p), p
 
 
+def test_mid_size_library_gets_the_large_first_level(built):
+    """2 000 sequences (626 k k-mers): an LDS-sized first level would have groups of 7.3 k-mers, which one-byte pilots cannot place at any
+    load — the builder then takes one pilot per 3 k-mers (first level in global memory, as for c5) instead of giving up on the perfect hash
+    and with it on the anchor kernels (found by scripts/fuzz_gpu.py: such libraries ran on the wave-per-read kernels only)."""
+    from oracle import oracle
+    _, _, strs, _ = library_strings(40, 50, locus_len=1098, seed=3128)
+    ix = engine.Index(strs, 20)
+    st = ix.stats()
+    assert st["ph_table_bytes"] > 0 and st["ph_pilot_bytes"] > 150_000 and st["anchor_bytes"] > 0, st
+    ox = oracle.OracleIndex(strs, 20)
+    rng = np.random.default_rng(2)
+    comp = str.maketrans("ACGT", "TGCA")
+    probes = [s[i:i + 20] for s in strs[::41] for i in range(0, len(s) - 19, 7)]
+    probes += [p.translate(comp)[::-1] for p in probes[::3]] + ["".join("ACGT"[c] for c in rng.integers(0, 4, 20)) for _ in range(300)]
+    for p in probes:
+        assert ix.query(p) == ox.query(p), p                   # (nb_index_query cross-checks the perfect-hash table on every call)
+
+
 def test_colour_ids_ascend_by_size(built):
     """The kernels seed the intersection with min(colour id): ids must be ordered by class size."""
     _, _, strs, _ = library_strings(3, 7, 300, seed=5)
