@@ -49,7 +49,7 @@ struct AnchorHead {
   int pilot_lds_bytes, rec_dwords;                   // dynamic LDS: [pilots][per wave: rec_dwords x 64 dwords]
   long long text_words, sparse_words; int W;         // sizes, for the bounds-checked debug build (-DNB_ANCHOR_PROF -DNB_ANCHOR_CHECK)
   MateRes* mate_out;                                 // MATE kernels: one raw result per sequence instead of SPEC §4 / interning / outputs
-  int dbg;                                           // -DNB_ANCHOR_PROF only (NB_ANCHOR_DBG): 1 = sparse loads, 2 = table entries, 4 = text loads redirected to element 0 (WRONG results: cost attribution)
+  int dbg;                                           // NB_ANCHOR_DBG: 8 = no LDS cache of class counts; -DNB_ANCHOR_PROF only: 1 = sparse loads, 2 = table entries, 4 = text loads redirected to element 0 (WRONG results: cost attribution)
   uint32_t* scan_counts; long long scan_seg;         // scan list: workgroup b owns entries [b * scan_seg, ...) of ll.rc_list and counts them in
                                                      // scan_counts[b] (one LDS atomic per wave instead of one contended device atomic)
   // Stragglers. A wave-batch lasts as long as its slowest lane (c2: 18 rounds for reads that need 7 on average). First pass (retry_out set):
@@ -161,6 +161,11 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   __shared__ unsigned int s_scan_n, s_retry_n;
+  // counts of the workgroup's hot classes (direct-mapped by the low bits of the class id; ids are handed out in first-seen order, so the
+  // classes every wave meets have small, distinct ones): with a library of a few loci every wave adds to the same handful of counters,
+  // and atomics on one address serialise in the L2 — 250 sequences took 3.9 ms per 10 M reads where 500 took 3.1
+  constexpr int CACHE = 256;
+  __shared__ unsigned int s_ctag[CACHE], s_ccnt[CACHE];
   uint8_t* s_pilots = s_dyn;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
   const bool listed = h.retry_in != nullptr;     // second pass: this workgroup's segment of the retry list
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
   if (threadIdx.x == 0) { s_scan_n = listed ? h.scan_counts[blockIdx.x] : 0u; s_retry_n = 0; }
+  for (int i = threadIdx.x; i < CACHE; i += blockDim.x) { s_ctag[i] = NB_NO_CLASS; s_ccnt[i] = 0u; }
   if (PLDS)
     for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
       *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
@@ -535,7 +541,13 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
       cls = intern_lane2(T.ct, T.W, lead, lo, a0, NW > 1 ? a1 : 0ull);
       cls = (uint32_t)__shfl((int)cls, (int)leader);
       PROF_MARK(5);
-      if (lead && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], (unsigned long long)mult);
+      if (lead && cls != NB_NO_CLASS) {
+        const uint32_t slot = cls & (uint32_t)(CACHE - 1);
+        uint32_t tag = (h.dbg & 8) ? ~cls : s_ctag[slot];                            // (NB_ANCHOR_DBG=8: every count straight to memory, A/B runs)
+        if (tag == NB_NO_CLASS) { tag = atomicCAS(&s_ctag[slot], NB_NO_CLASS, cls); if (tag == NB_NO_CLASS) tag = cls; }
+        if (tag == cls) atomicAdd(&s_ccnt[slot], mult);                                // (flushed once per workgroup, below)
+        else atomicAdd(&T.ct.counts[cls], (unsigned long long)mult);
+      }
       if (active && final_) {
         atomicAdd(&s_reason[reason], 1u);
         if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
@@ -564,6 +576,9 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
 #endif
   __syncthreads();
   if (threadIdx.x == 0) { h.scan_counts[blockIdx.x] = s_scan_n; if (h.retry_out) h.retry_counts[blockIdx.x] = s_retry_n; }
+  if (!MATE)
+    for (int i = threadIdx.x; i < CACHE; i += blockDim.x)
+      if (s_ctag[i] != NB_NO_CLASS && s_ccnt[i]) atomicAdd(&tp->ct.counts[s_ctag[i]], (unsigned long long)s_ccnt[i]);
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
 
@@ -763,11 +778,13 @@ __global__ __launch_bounds__(256) void nb_anchor_pair_kernel(const MateRes* __re
 
 // dynamic LDS of one workgroup: first level of the table (if it fits next to >= 8 waves of records: *plds) + record staging of up to 16
 // waves (the kernels need ~110 VGPRs: 4 waves per SIMD)
+constexpr int64_t ANCHOR_LDS_BUDGET = (160 << 10) - 256 - 2048;   // dynamic LDS of the anchor kernels: 160 KB minus their static LDS (reason and list
+                                                                   // counters, 2 KB of hot-class counts)
 static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block, bool* plds) {
   const int nwb = (max_len + 31) / 32, nwn = (max_len + 63) / 64;
   const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4;
   int64_t pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
-  const int64_t budget = (160 << 10) - 256;
+  const int64_t budget = ANCHOR_LDS_BUDGET;
   *plds = pil + 8 * rec <= budget;
   if (const char* e = std::getenv("NB_ANCHOR_PLDS")) { if (e[0] == '0') *plds = false; }     // (A/B: first level read from L2 although it would fit)
   if (!*plds) pil = 0;
@@ -783,7 +800,7 @@ static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_blo
 
 template <int NR, int NW, bool PLDS, bool MATE>
 static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
-  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANCHOR_LDS_BUDGET));
   long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
   if (!PLDS && waves <= 8) blocks *= 2;                              // first level in global memory (large libraries: fabric-bound): 16 waves per CU
   if (const char* e = std::getenv("NB_ANCHOR_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) blocks = (long long)c->n_cu * v; }

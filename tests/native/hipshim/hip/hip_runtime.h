@@ -41,6 +41,7 @@ static inline uint64_t __brevll(uint64_t x) { return ((uint64_t)__brev((uint32_t
 static inline long long clock64() { return (long long)std::chrono::steady_clock::now().time_since_epoch().count(); }
 
 template <class T, class V> static inline T atomicAdd(T* p, V v) { const T old = *p; *p = (T)(old + (T)v); return old; }
+template <class T, class V, class W> static inline T atomicCAS(T* p, V cmp, W val) { const T old = *p; if (old == (T)cmp) *p = (T)val; return old; }
 template <class T, class V> static inline T atomicOr(T* p, V v) { const T old = *p; *p = (T)(old | (T)v); return old; }
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
