@@ -681,7 +681,10 @@ __global__ __launch_bounds__(1024) void nb_anchor_scan_kernel(AnchorHead h, cons
 template <int NW>
 __global__ __launch_bounds__(256) void nb_anchor_pair_kernel(const MateRes* __restrict__ m1, const MateRes* __restrict__ m2, int K, const LaneTail* __restrict__ tp) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  constexpr int CACHE = 256;                                  // counts of the workgroup's hot classes, as in nb_anchor_kernel
+  __shared__ unsigned int s_ctag[CACHE], s_ccnt[CACHE];
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < CACHE; i += blockDim.x) { s_ctag[i] = NB_NO_CLASS; s_ccnt[i] = 0u; }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -757,7 +760,13 @@ __global__ __launch_bounds__(256) void nb_anchor_pair_kernel(const MateRes* __re
     const bool fin = active && !redo;
     const Ori& P = pickR ? R : F;
     uint32_t cls = intern_lane2(T.ct, T.W, fin && call, P.lo, P.s0, NW > 1 ? P.s1 : 0ull);
-    if (fin && call && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], 1ull);
+    if (fin && call && cls != NB_NO_CLASS) {
+      const uint32_t slot = cls & (uint32_t)(CACHE - 1);
+      uint32_t tag = s_ctag[slot];
+      if (tag == NB_NO_CLASS) { tag = atomicCAS(&s_ctag[slot], NB_NO_CLASS, cls); if (tag == NB_NO_CLASS) tag = cls; }
+      if (tag == cls) atomicAdd(&s_ccnt[slot], 1u);
+      else atomicAdd(&T.ct.counts[cls], 1ull);
+    }
     if (fin) {
       atomicAdd(&s_reason[reason], 1u);
       if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
@@ -774,6 +783,8 @@ __global__ __launch_bounds__(256) void nb_anchor_pair_kernel(const MateRes* __re
   }
   __syncthreads();
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+  for (int i = threadIdx.x; i < CACHE; i += blockDim.x)
+    if (s_ctag[i] != NB_NO_CLASS && s_ccnt[i]) atomicAdd(&tp->ct.counts[s_ctag[i]], (unsigned long long)s_ccnt[i]);
 }
 
 // dynamic LDS of one workgroup: first level of the table (if it fits next to >= 8 waves of records: *plds) + record staging of up to 16

@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nimble_amd import engine, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
-names, seqs, _ = synth.synth_library(20, 50)
+loci, alleles = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (20, 50)
+names, seqs, _ = synth.synth_library(loci, alleles)
 strs = [synth.codes_to_str(s) for s in seqs]
 dev = torch.device("cuda:0")
 
