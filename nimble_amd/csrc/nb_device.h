@@ -267,6 +267,26 @@ struct LaneLists {
 struct LaneTail { DevClasses ct; BatchArgs a; LaneLists ll; int W; };
 
 #if defined(__HIPCC__)
+// Counts of a workgroup's hot classes in LDS (direct-mapped by the low bits of the class id, which are handed out in first-seen order: the
+// classes every wave meets have small, distinct ids). With a library of a few loci every read adds to the same handful of counters, and
+// atomics on one address serialise in the L2 (wave-per-read kernel, 20 sequences: 43.6 ms per 10 M reads against 16.7 for 1 000 sequences).
+// tag / cnt: COUNT_CACHE words each, set to NB_NO_CLASS / 0 before use; count_cache_flush after the workgroup's last read.
+constexpr int COUNT_CACHE = 256;
+__device__ __forceinline__ void count_cache_init(unsigned int* tag, unsigned int* cnt) {
+  for (int i = threadIdx.x; i < COUNT_CACHE; i += blockDim.x) { tag[i] = NB_NO_CLASS; cnt[i] = 0u; }
+}
+__device__ __forceinline__ void count_cache_add(unsigned int* tag, unsigned int* cnt, unsigned long long* counts, uint32_t cls, uint32_t mult) {
+  const uint32_t slot = cls & (uint32_t)(COUNT_CACHE - 1);
+  uint32_t t = tag[slot];
+  if (t == NB_NO_CLASS) { t = atomicCAS(&tag[slot], NB_NO_CLASS, cls); if (t == NB_NO_CLASS) t = cls; }
+  if (t == cls) atomicAdd(&cnt[slot], mult);
+  else atomicAdd(&counts[cls], (unsigned long long)mult);
+}
+__device__ __forceinline__ void count_cache_flush(const unsigned int* tag, const unsigned int* cnt, unsigned long long* counts) {   // (after a __syncthreads)
+  for (int i = threadIdx.x; i < COUNT_CACHE; i += blockDim.x)
+    if (tag[i] != NB_NO_CLASS && cnt[i]) atomicAdd(&counts[tag[i]], (unsigned long long)cnt[i]);
+}
+
 // per-lane interning of a set of at most two words {word index lo: a0, lo + 1: a1} in the shared class table; returns the class id or
 // NB_NO_CLASS. Same table protocol as intern_class (nb_kernels.hip): key = content hash (xor of one mixed word per non-zero (index, value)),
 // full-content verification through (spans, words).

@@ -651,7 +651,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   constexpr bool LDS_DESC = TW == 1 && (TRI || NR == 2);   // (wide class rows go through `packed` anyway: a loss on c5; one round of positions: neutral)
   __shared__ uint4 s_desc[LDS_DESC ? 4 : 1][LDS_DESC ? 2 * NR : 1][LDS_DESC ? 64 : 1];   // per wave: 3 residues x 2 halves of a 32-byte descriptor per lane
+  __shared__ unsigned int s_ctag[COUNT_CACHE], s_ccnt[COUNT_CACHE];                        // hot class counts (nb_device.h)
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  count_cache_init(s_ctag, s_ccnt);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
           DevClasses ct = ctv;
           if constexpr (TRI) { asm volatile("" ::: "memory"); ct = *ctp; }
           cls = intern_class<TW>(ct, ix.W, lane, acc);
-          if (cls != NB_NO_CLASS && lane == 0) atomicAdd(&ct.counts[cls], 1ull);
+          if (cls != NB_NO_CLASS && lane == 0) count_cache_add(s_ctag, s_ccnt, ct.counts, cls, 1u);
 #endif
         }
       } else reason = reasons[0] > reasons[1] ? reasons[0] : reasons[1];
@@ -762,6 +764,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_SE_WAVES
   }
   __syncthreads();
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&ctp->reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+  count_cache_flush(s_ctag, s_ccnt, ctp->counts);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -935,7 +938,9 @@ template <int NR, int TW, int MODE, bool CT>
 __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevClasses ct, BatchArgs a) {
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
   __shared__ uint64_t s_seq[4][GEN_WORDS];
+  __shared__ unsigned int s_ctag[COUNT_CACHE], s_ccnt[COUNT_CACHE];                        // hot class counts (nb_device.h)
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  count_cache_init(s_ctag, s_ccnt);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1006,7 +1011,7 @@ __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevC
 #pragma unroll
         for (int t = 0; t < TW; ++t) acc[t] = pickR ? R.set[t] : F.set[t];
         cls = intern_class<TW>(ct, ix.W, lane, acc);
-        if (cls != NB_NO_CLASS && lane == 0) atomicAdd(&ct.counts[cls], 1ull);
+        if (cls != NB_NO_CLASS && lane == 0) count_cache_add(s_ctag, s_ccnt, ct.counts, cls, 1u);
       }
     } else reason = F.reason > R.reason ? F.reason : R.reason;
     if (lane == 0) {
@@ -1018,6 +1023,7 @@ __global__ __launch_bounds__(256) void nb_align_general_kernel(DevIndex ix, DevC
   }
   __syncthreads();
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+  count_cache_flush(s_ctag, s_ccnt, ct.counts);
 }
 
 // ------------------------------------------------------------------------------------------------------------

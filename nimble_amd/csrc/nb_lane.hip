@@ -54,12 +54,14 @@ template <int NR, int PASS>
 __global__ __launch_bounds__(768) void nb_lane_kernel(LaneHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
+  __shared__ unsigned int s_ctag[COUNT_CACHE], s_ccnt[COUNT_CACHE];                        // hot class counts (nb_device.h)
   uint8_t* s_pilots = s_dyn;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wpb = (int)(blockDim.x >> 6);
   uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;   // dword j of this lane's record at rec[j * 64 + lane]
   if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
+  count_cache_init(s_ctag, s_ccnt);
   for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)      // first level of the table -> LDS (16 bytes per thread and step)
     *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
   __syncthreads();
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(768) void nb_lane_kernel(LaneHead h, const LaneTail
       }
     } else if (active) final_ = true;                                         // shorter than k: TOO_SHORT
     cls = intern_lane(T.ct, T.W, call, lo, a0);                               // (every lane takes part in the loop, see intern_lane)
-    if (call && cls != NB_NO_CLASS) atomicAdd(&T.ct.counts[cls], 1ull);
+    if (call && cls != NB_NO_CLASS) count_cache_add(s_ctag, s_ccnt, T.ct.counts, cls, 1u);
     if (active && final_) {
       atomicAdd(&s_reason[reason], 1u);
       if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(768) void nb_lane_kernel(LaneHead h, const LaneTail
   }
   __syncthreads();
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
+  count_cache_flush(s_ctag, s_ccnt, tp->ct.counts);
 }
 
 // dynamic LDS of one workgroup for reads up to max_len: first level of the table + record staging of `waves` waves; 0 if it cannot fit
@@ -306,7 +309,7 @@ int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block) {
   if (!c->has_ph) return 0;
   const int nwb = (max_len + 31) / 32, nwn = (max_len + 63) / 64;
   const int64_t rec = (int64_t)(2 * (nwb + nwn) + 2) * 64 * 4, pil = ((int64_t)c->ph.n_groups + 15) / 16 * 16;
-  const int64_t budget = (160 << 10) - 256;
+  const int64_t budget = (160 << 10) - 256 - 2048;   // (minus the kernel's static LDS: reason counters, 2 KB of hot-class counts)
   int w = 12;                                  // measured on c2: 12 waves per workgroup 8.2 ms, 16 waves 8.5 ms, 8 waves 8.5 ms
   if (const char* e = std::getenv("NB_LANE_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= LANE_MAX_WAVES) w = v; }
   while (w > 0 && pil + (int64_t)w * rec > budget) --w;
@@ -318,7 +321,7 @@ int64_t lane_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_block) {
 template <int NR, int PASS>
 static int launch_lane_t(nb_ctx* c, const LaneHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
   // (per launch: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may hold contexts on several)
-  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_lane_kernel<NR, PASS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_lane_kernel<NR, PASS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256 - 2048));
   long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
   const long long need = PASS == 0 ? (h.n + 64LL * waves - 1) / (64LL * waves) : blocks;     // pass 1: the list length is only known on the device
   if (blocks > need) blocks = need;
