@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--loci", type=int, default=None)
     ap.add_argument("--alleles", type=int, default=None)
     ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--foreign", type=float, default=None, help="fraction of uniform random reads in the synthetic batch (default: synth's 0.10); sweeps only")
+    ap.add_argument("--err", type=float, default=None, help="substitution rate of the library-derived reads (default: synth's 0.01); sweeps only")
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="upper bound of the reads timed on the CPU baseline (rank 0, N=1 only); the "
                     "actual sample is sized from a calibration slice so that the timed call runs about --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="target wall time of the timed CPU-baseline call")
@@ -196,7 +198,12 @@ def main():
     seed = preset["seed"] if world == 1 else 4 + rank
     n_keep = max(args.parity_sample, 0 if (args.no_cpu_baseline or world > 1) else args.cpu_sample) if rank == 0 else 0
     t0 = time.time()
-    res = synth.synth_reads_packed_torch(seqs, n, L, seed, dev, return_codes_of_first=min(n_keep, n))
+    shape_kw = {}
+    if args.foreign is not None:
+        shape_kw["frac_random"] = args.foreign
+    if args.err is not None:
+        shape_kw["err"] = args.err
+    res = synth.synth_reads_packed_torch(seqs, n, L, seed, dev, return_codes_of_first=min(n_keep, n), **shape_kw)
     d_reads, first_codes = res if n_keep else (res, None)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
