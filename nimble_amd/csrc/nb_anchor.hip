@@ -57,7 +57,6 @@ struct AnchorHead {
   // the scan list) and the wave moves on. Second pass (retry_in set, same grid): workgroup b maps its own segment, reads from scratch, in waves
   // that hold nothing but long walks.
   uint32_t* retry_out; const uint32_t* retry_in; uint32_t* retry_counts; int retry_lanes, retry_rounds;
-  uint32_t* ring; uint32_t* wres;                    // pipelined form: per-wave FIFO of stream-order records, per-read walk results
 };
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
@@ -675,588 +674,6 @@ __global__ __launch_bounds__(1024) void nb_anchor_scan_kernel(AnchorHead h, cons
   if (threadIdx.x == 0 && s_nohit) atomicAdd(&tp->ct.reasons[NB_NO_HIT], (unsigned long long)s_nohit);
 }
 
-// =====================================================================================================================================
-// Pipelined form of the anchor kernel (the default; NB_ANCHOR_PIPE=0 selects nb_anchor_kernel above for A/B runs).
-//
-// In nb_anchor_kernel a wave maps 64 reads in lock-step and the slowest lane decides: c2's reads need 7.3 rounds on average, their waves 18
-// (profiles/r02y_rounds_histogram.txt) — 40 % lane utilisation in the part of the kernel that takes two thirds of its time. Here the walk of
-// a read is decoupled from the work before and after it:
-//
-//   produce   (nb_anchor_walk_kernel, all 64 lanes busy) the next 64 reads of the wave: three probes decide the orientation, the record is
-//             written IN STREAM ORDER (reverse-complemented if need be: dwords fetched in reverse order, bit-reversed, complemented, funnel-
-//             shifted) to a wave-private FIFO of RING slots in global memory (L2 / Infinity Cache resident: 12 KB per wave); reads without
-//             any probe hit go on the scan list, reads shorter than k are settled at once.
-//   walk      the rounds of nb_anchor_kernel, but a lane whose walk is over stores its result (WRes: coverage, flags, class words, the
-//             pending run, first-seed facts, cover mask: 64 B in wres[read]) and starts on the record it had bound before — copied from the
-//             FIFO into registers a round earlier, so the refill costs no idle round — and binds the next free FIFO entry (wave ballot +
-//             prefix count: no atomics, nothing shared between waves). Lanes never wait for each other; when the FIFO runs low the wave
-//             leaves the rounds (walks stay in their registers and LDS columns), produces 64 more records and comes back.
-//   finish    (nb_anchor_finish_kernel, all lanes busy) per read: the pending class AND, the left extension from the first seed, the
-//             other orientation's seed-scan positions, SPEC §4, interning, outputs and lists — the tail of nb_anchor_kernel, fed from wres.
-//
-// Exits: a wave leaves when its share of the input is produced, its FIFO is empty and no lane holds a read; every walking lane advances in
-// every round (and is cut off after 6 L + 16 rounds like the waves of nb_anchor_kernel), so every wave reaches that point.
-constexpr int PIPE_RING = 128;     // FIFO slots per wave (power of two); a slot is written again PIPE_RING - 64 - PIPE_LOW reads later at the earliest
-constexpr int PIPE_LOW = 32;       // produce when fewer than this many records are waiting
-template <int NR> struct PipeShape {
-  static constexpr int MAXBD = 4 * NR + 2, MAXND = 2 * NR + 2;                 // dwords of bases / of N bits of the longest record (max_len <= 64 NR + 30)
-  static constexpr int SLOT_DW = (MAXBD + MAXND + 2 + 3) & ~3;                 // FIFO slot: [bases][N bits][read index][length | rc << 16]
-};
-template <int NR, int NW> struct WResShape { static constexpr int DW = (5 + 2 * NW + 2 * NR + 3) & ~3; };
-// wres[read]: d0 = coverage | flags << 16 | walked << 24 | rc << 25; d1 = lo | pending w0 << 16; class words; pending run text position;
-// pending n | first-seed position << 8 | its left room << 24; first-seed anchor text position; cover mask
-
-constexpr uint32_t WF_SEEDED = 1u, WF_STARTED = 2u, WF_SLOW = 4u, WF_HARD = 8u, WF_OPP = 16u, WF_LEXT = 32u, WF_ERR = 64u, WF_STEP = 128u;
-constexpr uint32_t WF_REDO = WF_SLOW | WF_HARD | WF_OPP | WF_LEXT | WF_ERR;
-
-__device__ __forceinline__ uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
-
-template <int NR, int NW, bool PLDS, bool MATE>
-__global__ __launch_bounds__(1024) void nb_anchor_walk_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-  __shared__ unsigned int s_scan_n, s_short;
-  uint8_t* s_pilots = s_dyn;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wpb = (int)(blockDim.x >> 6);
-  uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
-  if (threadIdx.x == 0) { s_scan_n = 0; s_short = 0; }
-  if (PLDS)
-    for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
-      *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
-  __syncthreads();
-  using PS = PipeShape<NR>;
-  constexpr int SLOT_DW = PS::SLOT_DW, MAXBD = PS::MAXBD, MAXND = PS::MAXND, WDW = WResShape<NR, NW>::DW;
-  const int K = h.K;
-  const uint64_t kmask = (1ull << (2 * K)) - 1;
-  const uint32_t nkmask = (1u << K) - 1u;
-  const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1, nbd = 2 * nwb, nd = 2 * nwn;
-  const uint64_t lt = (1ull << lane) - 1;
-  // this wave's share of the input: whole 64-read batches, dealt evenly
-  const long long nwaves = (long long)gridDim.x * wpb, gw = (long long)blockIdx.x * wpb + wave, nbatch = (h.n + 63) >> 6;
-  long long in_pos = ((gw * nbatch) / nwaves) << 6;
-  long long in_end = (((gw + 1) * nbatch) / nwaves) << 6; if (in_end > h.n) in_end = h.n;
-  uint32_t* ring = h.ring + (size_t)gw * (size_t)(PIPE_RING * SLOT_DW);
-  uint32_t rd_w = 0, rd_t = 0;                   // records written to / taken from the FIFO (wave-uniform)
-
-  // ---- produce: orientation and stream-order record of the next 64 reads ----
-  auto produce = [&]() {
-    const long long i = in_pos + lane;
-    const bool active = i < in_end;
-    const uint32_t r = (uint32_t)(active ? i : in_pos);
-    int L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len;
-    const uint32_t* rp = reinterpret_cast<const uint32_t*>(h.reads + (size_t)r * h.stride);   // [bases: nbd dwords][N bits: nd dwords]
-    const int last = L - K;
-    int votes = 0; bool any = false;
-    {
-      LookKey pk[3]; bool pv[3];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        int p = u == 0 ? 0 : (u == 1 ? last >> 1 : last); if (p < 0) p = 0;
-        const int j = p >> 4; const uint32_t sh = 2u * ((uint32_t)p & 15u);
-        const U3 t3 = *reinterpret_cast<const U3*>(rp + (CHK(j + 2 < nbd + nd, 15) ? j : 0));
-        const uint64_t lo = ((uint64_t)t3.b << 32) | t3.a;
-        const uint64_t w = sh ? ((lo >> sh) | ((uint64_t)t3.c << (64u - sh))) : lo;
-        const int an = p >> 5;
-        const uint32_t n0 = rp[nbd + (an < nd ? an : 0)], n1 = an + 1 < nd ? rp[nbd + an + 1] : 0u;
-        uint32_t nn = (uint32_t)((((uint64_t)n1 << 32) | n0) >> ((uint32_t)p & 31u));
-        const int left = L - p;
-        nn |= left >= 32 ? 0u : (left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << left));
-        pv[u] = active && last >= 0 && (nn & nkmask) == 0;
-        pk[u] = anchor_lookup_key<PLDS>(h, s_pilots, w & kmask, pv[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const uint32_t d = pk[u].d;
-        if (pv[u] && d < 4u) { any = true; if (!(d & 2u)) votes += ((d & 1u) == (pk[u].o ? 1u : 0u)) ? 1 : -1; }
-      }
-    }
-    const bool rcn = votes < 0;
-    const bool walk = active && last >= 0 && any, scan = active && last >= 0 && !any, shrt = active && last < 0;
-    uint32_t o[SLOT_DW];
-    {   // bases: forward as they are; reverse complement = dwords in reverse order, bit-reversed, pairs swapped back, complemented, and the
-        // read's end shifted down to position 0 (what Rec::stream_rc does in LDS)
-      const int sB = 2 * (16 * nbd - L), qd = sB >> 5; const uint32_t rB = rcn ? ((uint32_t)sB & 31u) : 0u;
-      auto yb = [&](int j) -> uint32_t {
-        const int m = j + qd, idx = rcn ? nbd - 1 - m : j;
-        const bool ok = rcn ? (m < nbd) : (j < nbd);
-        uint32_t v = rp[ok ? idx : 0];
-        if (rcn) { v = __brev(v); v = ~(((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u)); }
-        return ok ? v : 0u;
-      };
-      uint32_t y0 = yb(0);
-#pragma unroll
-      for (int j = 0; j < MAXBD; ++j) { const uint32_t y1 = j < nbd ? yb(j + 1) : 0u; o[j] = j < nbd ? funnel32(y1, y0, rB) : 0u; y0 = y1; }
-    }
-    {
-      const int sN = 32 * nd - L, qd = sN >> 5; const uint32_t rN = rcn ? ((uint32_t)sN & 31u) : 0u;
-      auto zb = [&](int j) -> uint32_t {
-        const int m = j + qd, idx = rcn ? nd - 1 - m : j;
-        const bool ok = rcn ? (m < nd) : (j < nd);
-        uint32_t v = rp[nbd + (ok ? idx : 0)];
-        if (rcn) v = __brev(v);
-        return ok ? v : 0u;
-      };
-      uint32_t z0 = zb(0);
-#pragma unroll
-      for (int j = 0; j < MAXND; ++j) { const uint32_t z1 = j < nd ? zb(j + 1) : 0u; o[MAXBD + j] = j < nd ? funnel32(z1, z0, rN) : 0u; z0 = z1; }
-    }
-    o[MAXBD + MAXND] = r; o[MAXBD + MAXND + 1] = (uint32_t)L | ((rcn ? 1u : 0u) << 16);
-#pragma unroll
-    for (int j = MAXBD + MAXND + 2; j < SLOT_DW; ++j) o[j] = 0u;
-    const uint64_t mw = __ballot(walk);
-    if (mw) {
-      NB_WAIT_VMCNT0();                          // records bound earlier have reached their lanes' registers before their slots are written again
-      if (walk) {
-        uint32_t* sp = ring + (size_t)((rd_w + (uint32_t)__popcll(mw & lt)) & (uint32_t)(PIPE_RING - 1)) * SLOT_DW;
-#pragma unroll
-        for (int q = 0; q < SLOT_DW / 4; ++q) { uint4 v; v.x = o[4 * q]; v.y = o[4 * q + 1]; v.z = o[4 * q + 2]; v.w = o[4 * q + 3]; *reinterpret_cast<uint4*>(sp + 4 * q) = v; }
-      }
-      NB_WAIT_VMCNT0();                          // ... and these are written before any lane of the wave binds one of them
-      rd_w += (uint32_t)__popcll(mw);
-    }
-    if (active && !walk) h.wres[(size_t)r * WDW] = 0u;                        // (not walked: the finish kernel passes over it)
-    const uint64_t ms = __ballot(scan);
-    if (ms) {
-      uint32_t b0 = 0;
-      if (lane == 0) b0 = atomicAdd(&s_scan_n, (uint32_t)__popcll(ms));
-      b0 = __builtin_amdgcn_readfirstlane(b0);
-      if (scan) tp->ll.rc_list[(size_t)blockIdx.x * (size_t)h.scan_seg + b0 + (uint32_t)__popcll(ms & lt)] = r;
-    }
-    if (MATE) {
-      if (shrt || scan) { MateRes mr; mr.info = (shrt ? MATE_SHORT : MATE_SCAN) << 17; mr.lo = 0u; mr.a0 = 0ull; mr.a1 = 0ull; h.mate_out[r] = mr; }
-    } else if (shrt) {
-      const BatchArgs& a = tp->a;
-      atomicAdd(&s_short, 1u);
-      if (a.out_class) a.out_class[r] = NB_NO_CLASS;
-      if (a.out_info) a.out_info[r] = (uint32_t)NB_TOO_SHORT << 16;
-      if (a.out_cov) a.out_cov[r] = 0ull;
-    }
-    in_pos += 64;
-  };
-
-  // ---- per-lane state: the record bound for later (stage), the walk in progress ----
-  uint32_t stage[SLOT_DW];
-#pragma unroll
-  for (int j = 0; j < SLOT_DW; ++j) stage[j] = 0u;
-  bool hasnext = false, has_cur = false;
-  constexpr int SEEK = 0, STEP = 1, EXT = 2, DONE = 3;
-  int mode = DONE;
-  uint32_t r = 0; int L = 0; bool rcf = false;
-  uint32_t fl = 0;
-  int pos = 0, cov = 0;
-  uint32_t lo = 0; uint64_t a0 = 0, a1 = 0;
-  uint32_t run_t = 0, run_w0 = 0; int run_q = 0, steps = 0, maxsteps = 0;
-  uint32_t p_t = 0, p_n = 0, p_w0 = 0;
-  Mask<NR> cover;
-#pragma unroll
-  for (int wi = 0; wi < NR; ++wi) cover.w[wi] = 0;
-  int ls_q = 0, ls_room = 0; uint32_t ls_t = 0;
-  int lrounds = 0;
-
-  auto fold = [&](uint64_t v0, uint64_t v1, uint32_t w0) {
-    const bool first = !(fl & WF_STARTED);
-    a0 = first ? v0 : ((w0 == lo) ? (a0 & v0) : 0ull);
-    if (NW > 1) a1 = first ? v1 : ((w0 == lo) ? (a1 & v1) : 0ull);
-    lo = first ? w0 : lo;
-    fl |= WF_STARTED;
-  };
-  auto range_and = [&](uint32_t t, uint32_t n, uint64_t& v0, uint64_t& v1) {
-    const int lv = 31 - __builtin_clz(n);
-    uint32_t off = n - (1u << lv);
-    if (!CHK(n >= 1u && n < 256u && ((long long)lv * h.T + t + off + 1) * NW <= h.sparse_words, 13)) { t = 0u; off = 0u; }
-    const uint64_t* sp = h.sparse + ((size_t)(n >= 1u && n < 256u ? lv : 0) * (size_t)h.T + t) * NW;
-    if (NW == 1) { v0 = sp[0] & sp[off]; v1 = 0ull; }
-    else {
-      const uint4 x = *reinterpret_cast<const uint4*>(sp), y = *reinterpret_cast<const uint4*>(sp + 2 * (size_t)off);
-      v0 = (((uint64_t)x.y << 32) | x.x) & (((uint64_t)y.y << 32) | y.x);
-      v1 = (((uint64_t)x.w << 32) | x.z) & (((uint64_t)y.w << 32) | y.z);
-    }
-  };
-
-  for (;;) {
-    while (in_pos < in_end && (rd_w - rd_t) < (uint32_t)PIPE_LOW) produce();
-    for (;;) {
-      // ---- finished walks hand their result over; bound records start; lanes without a bound record bind one ----
-      const bool fin = has_cur && mode == DONE;
-      if (__ballot(fin)) {
-        if (fin) {
-          uint32_t d[WDW];
-#pragma unroll
-          for (int j = 0; j < WDW; ++j) d[j] = 0u;
-          d[0] = (uint32_t)(cov & 0xFFFF) | ((fl & 0xFFu) << 16) | (1u << 24) | ((rcf ? 1u : 0u) << 25);
-          d[1] = (lo & 0xFFFFu) | (p_w0 << 16);
-          d[2] = (uint32_t)a0; d[3] = (uint32_t)(a0 >> 32);
-          if (NW > 1) { d[4] = (uint32_t)a1; d[5] = (uint32_t)(a1 >> 32); }
-          constexpr int B = 2 + 2 * NW;
-          d[B] = p_t; d[B + 1] = (p_n & 0xFFu) | (((uint32_t)ls_q & 0xFFFFu) << 8) | (((uint32_t)ls_room & 0xFFu) << 24); d[B + 2] = ls_t;
-#pragma unroll
-          for (int wi = 0; wi < NR; ++wi) { d[B + 3 + 2 * wi] = (uint32_t)cover.w[wi]; d[B + 4 + 2 * wi] = (uint32_t)(cover.w[wi] >> 32); }
-          uint32_t* wp = h.wres + (size_t)r * WDW;
-#pragma unroll
-          for (int q = 0; q < WDW / 4; ++q) { uint4 v; v.x = d[4 * q]; v.y = d[4 * q + 1]; v.z = d[4 * q + 2]; v.w = d[4 * q + 3]; *reinterpret_cast<uint4*>(wp + 4 * q) = v; }
-          has_cur = false;
-        }
-      }
-      const bool st = !has_cur && hasnext;
-      if (__ballot(st)) {
-        if (st) {
-          uint32_t* col = rec + lane;
-#pragma unroll
-          for (int j = 0; j < MAXBD; ++j) if (j < nbd) col[j * 64] = stage[j];
-#pragma unroll
-          for (int j = 0; j < MAXND; ++j) if (j < nd) col[(nbd + j) * 64] = stage[MAXBD + j];
-          col[(nbd + nd) * 64] = 0u; col[(nbd + nd + 1) * 64] = 0u;
-          r = stage[MAXBD + MAXND]; L = (int)(stage[MAXBD + MAXND + 1] & 0xFFFFu); rcf = ((stage[MAXBD + MAXND + 1] >> 16) & 1u) != 0;
-          has_cur = true; hasnext = false; mode = SEEK;
-          fl = 0; pos = 0; cov = 0; lo = 0; a0 = 0; a1 = 0; run_t = 0; run_w0 = 0; run_q = 0; steps = 0; maxsteps = 0; p_t = 0; p_n = 0; p_w0 = 0;
-#pragma unroll
-          for (int wi = 0; wi < NR; ++wi) cover.w[wi] = 0;
-          ls_q = 0; ls_room = 0; ls_t = 0; lrounds = 0;
-        }
-      }
-      {
-        const uint32_t avail = rd_w - rd_t;
-        const uint64_t mb = __ballot(!hasnext);
-        if (mb && avail) {
-          const uint32_t pre = (uint32_t)__popcll(mb & lt);
-          if (!hasnext && pre < avail) {
-            const uint32_t* sp = ring + (size_t)((rd_t + pre) & (uint32_t)(PIPE_RING - 1)) * SLOT_DW;
-#pragma unroll
-            for (int q = 0; q < SLOT_DW / 4; ++q) {
-              const uint4 v = *reinterpret_cast<const uint4*>(sp + 4 * q);
-              stage[4 * q] = v.x; stage[4 * q + 1] = v.y; stage[4 * q + 2] = v.z; stage[4 * q + 3] = v.w;
-            }
-            hasnext = true;
-          }
-          const uint32_t nb_ = (uint32_t)__popcll(mb);
-          rd_t += nb_ < avail ? nb_ : avail;
-        }
-      }
-      const uint64_t cur = __ballot(has_cur);
-      if (in_pos < in_end && (rd_w - rd_t) < (uint32_t)PIPE_LOW) break;          // the FIFO runs low: produce (walks stay where they are)
-      if (!cur) { if (!__ballot(hasnext)) break; continue; }                     // (bound just now: they start in the next pass)
-
-      // ---- one round of every walk in progress: at most one table lookup and one 32-base comparison (nb_anchor_kernel's rounds) ----
-      const Rec R{rec + lane, nbd, nd, L};
-      const int last = L - K;
-      if (__ballot(mode == SEEK || mode == STEP)) {
-        const bool act = mode == SEEK || mode == STEP;
-        const bool step = mode == STEP;
-        const int q = act ? (step ? pos - K + 1 : pos) : 0;
-        uint64_t w; uint32_t nn; R.get32(q - (step ? 1 : 0), w, nn);
-        const uint32_t pb = (uint32_t)w & 3u;
-        const uint64_t x = (step ? (w >> 2) : w) & kmask;
-        const bool valid = act && (((step ? (nn >> 1) : nn) & nkmask) == 0);
-        const bool havep = act && p_n != 0u;
-        uint64_t s0 = ~0ull, s1 = ~0ull;
-        if (havep) range_and(p_t, p_n, s0, s1);
-        const Look k = anchor_lookup<PLDS>(h, s_pilots, x, valid);
-        const uint32_t d = k.e.x ^ k.want, pay = k.e.y;
-        if (havep) { fold(s0, s1, p_w0); p_n = 0u; }
-        const bool found = valid && d < 4u, both = found && (d & 2u);
-        const bool hS = found && !both && ((d & 1u) == (k.o ? 1u : 0u));
-        fl |= (both ? WF_HARD : 0u) | ((found && !both && !hS) ? WF_OPP : 0u);
-        const bool ok = hS && (!step || ((pay >> (4u + pb)) & 1u));
-        if (ok) {
-          if (!step && !(fl & WF_SEEDED) && q >= L / 5 && q > 0) {
-            fl |= WF_LEXT; ls_q = q; ls_t = k.e.z; ls_room = (int)((k.e.w >> 8) & 0x7Fu);
-          }
-          fl = (fl & ~WF_STEP) | (step ? WF_STEP : 0u) | WF_SEEDED;
-          run_t = k.e.z; run_w0 = k.e.w >> 16; run_q = q; steps = 0;
-          fl |= (k.e.w & ANCHOR_WIDE) ? WF_SLOW : 0u;
-          const int room = (int)(k.e.w & 0xFFu), rem = L - (q + K);
-          maxsteps = room < rem ? room : rem;
-          mode = EXT;
-        } else if (act) {
-#pragma unroll
-          for (int wi = 0; wi < NR; ++wi) cover.w[wi] |= ((q >> 6) == wi) ? (1ull << (q & 63)) : 0ull;
-          if (step) mode = pos > last ? DONE : SEEK;
-          else { pos += 3; mode = pos > last ? DONE : SEEK; }
-        }
-      }
-      if (__ballot(mode == EXT)) {
-        const bool ex = mode == EXT;
-        bool fin2 = ex;
-        if (ex && steps < maxsteps) {
-          uint64_t sw; uint32_t sn; R.get32(run_q + K + steps, sw, sn);
-          uint32_t tb = run_t + (uint32_t)(K + steps);
-          if (!CHK((long long)(tb >> 4) + 3 <= h.text_words, 12)) tb = 0u;
-          const U3 tw3 = *reinterpret_cast<const U3*>(h.text + (tb >> 4));
-          const uint32_t sh = 2u * (tb & 15u);
-          const uint64_t t01 = ((uint64_t)tw3.b << 32) | tw3.a;
-          const uint64_t tw = sh ? ((t01 >> sh) | ((uint64_t)tw3.c << (64u - sh))) : t01;
-          const uint64_t df = sw ^ tw;
-          const uint64_t m2 = (df | (df >> 1)) & 0x5555555555555555ull;
-          const int fm = m2 ? (__builtin_ctzll(m2) >> 1) : 32;
-          const int fn = sn ? __builtin_ctz(sn) : 32;
-          const int m = fm < fn ? fm : fn;
-          const int room_left = maxsteps - steps;
-          steps += m < room_left ? m : room_left;
-          fin2 = (m < 32) || steps >= maxsteps;
-        }
-        if (fin2) {
-          cov += ((fl & WF_STEP) ? 1 : K) + steps;
-          p_t = run_t; p_n = (uint32_t)steps + 1u; p_w0 = run_w0;
-          set_range<NR>(cover, run_q, run_q + steps);
-          pos = run_q + K + steps;
-          mode = pos >= L ? DONE : STEP;
-        }
-      }
-      if (mode != DONE && ++lrounds > 6 * h.max_len + 16) { fl |= WF_ERR; mode = DONE; }   // (cannot happen: every round advances a walking lane)
-    }
-    if (in_pos >= in_end && rd_w == rd_t && !__ballot(has_cur || hasnext)) break;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    h.scan_counts[blockIdx.x] = s_scan_n;
-    if (!MATE && s_short) atomicAdd(&tp->ct.reasons[NB_TOO_SHORT], (unsigned long long)s_short);
-  }
-}
-
-// finish: everything nb_anchor_kernel does after its rounds, for the reads nb_anchor_walk_kernel walked (wres). One read per lane, all lanes busy.
-template <int NR, int NW, bool PLDS, bool MATE>
-__global__ __launch_bounds__(1024) void nb_anchor_finish_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-  __shared__ unsigned int s_reason[NB_NUM_REASONS];
-  constexpr int CACHE = 256;
-  __shared__ unsigned int s_ctag[CACHE], s_ccnt[CACHE];
-  uint8_t* s_pilots = s_dyn;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wpb = (int)(blockDim.x >> 6);
-  uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
-  if (threadIdx.x < NB_NUM_REASONS) s_reason[threadIdx.x] = 0;
-  for (int i = threadIdx.x; i < CACHE; i += blockDim.x) { s_ctag[i] = NB_NO_CLASS; s_ccnt[i] = 0u; }
-  if (PLDS)
-    for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
-      *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
-  __syncthreads();
-  constexpr int WDW = WResShape<NR, NW>::DW;
-  const long long nwaves = (long long)gridDim.x * wpb;
-  const int K = h.K;
-  const uint64_t kmask = (1ull << (2 * K)) - 1;
-  const uint32_t nkmask = (1u << K) - 1u;
-  const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1;
-  const uint64_t lt = (1ull << lane) - 1;
-  constexpr int MAXW = 3 * NR + 2;
-  uint64_t nxt[MAXW];
-  const long long first = ((long long)blockIdx.x * wpb + wave) * 64, hop = nwaves * 64;
-  auto fetch = [&](long long b) {
-    const long long i = b + lane;
-    const uint64_t* __restrict__ rp = h.reads + (size_t)(i < h.n ? i : 0) * h.stride;
-#pragma unroll
-    for (int j = 0; j < MAXW; ++j) nxt[j] = (j < nwb + nwn && i < h.n) ? rp[j] : 0ull;
-  };
-  if (first < h.n) fetch(first);
-  for (long long base = first; base < h.n; base += hop) {
-    const long long idx = base + lane;
-    const uint32_t r = (uint32_t)(idx < h.n ? idx : 0);
-    uint32_t d[WDW];
-    {
-      const uint32_t* wp = h.wres + (size_t)r * WDW;
-#pragma unroll
-      for (int q = 0; q < WDW / 4; ++q) {
-        const uint4 v = *reinterpret_cast<const uint4*>(wp + 4 * q);
-        d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
-      }
-    }
-    const bool active = idx < h.n && ((d[0] >> 24) & 1u);
-    int L = 0;
-    if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
-    Rec R{rec + lane, 2 * nwb, 2 * nwn, L};
-#pragma unroll
-    for (int j = 0; j < MAXW; ++j) if (j < nwb + nwn) { R.at(2 * j) = (uint32_t)nxt[j]; R.at(2 * j + 1) = (uint32_t)(nxt[j] >> 32); }
-    R.at(2 * (nwb + nwn)) = 0u; R.at(2 * (nwb + nwn) + 1) = 0u;
-    if (base + hop < h.n) fetch(base + hop);
-    const int last = L - K;
-    const bool rcf = active && ((d[0] >> 25) & 1u);
-    if (rcf) R.stream_rc();
-    uint32_t fl = active ? ((d[0] >> 16) & 0xFFu) : 0u;
-    int cov = active ? (int)(d[0] & 0xFFFFu) : 0;
-    uint32_t lo = d[1] & 0xFFFFu; const uint32_t p_w0 = d[1] >> 16;
-    uint64_t a0 = ((uint64_t)d[3] << 32) | d[2], a1 = NW > 1 ? (((uint64_t)d[5 < WDW ? 5 : 0] << 32) | d[4 < WDW ? 4 : 0]) : 0ull;
-    constexpr int B = 2 + 2 * NW;
-    const uint32_t p_t = d[B], p_n = active ? (d[B + 1] & 0xFFu) : 0u;
-    const int ls_q = (int)((d[B + 1] >> 8) & 0xFFFFu), ls_room = (int)(d[B + 1] >> 24); const uint32_t ls_t = d[B + 2];
-    Mask<NR> cover;
-#pragma unroll
-    for (int wi = 0; wi < NR; ++wi) cover.w[wi] = ((uint64_t)d[B + 4 + 2 * wi] << 32) | d[B + 3 + 2 * wi];
-    auto fold = [&](uint64_t v0, uint64_t v1, uint32_t w0) {
-      const bool first_ = !(fl & WF_STARTED);
-      a0 = first_ ? v0 : ((w0 == lo) ? (a0 & v0) : 0ull);
-      if (NW > 1) a1 = first_ ? v1 : ((w0 == lo) ? (a1 & v1) : 0ull);
-      lo = first_ ? w0 : lo;
-      fl |= WF_STARTED;
-    };
-    auto range_and = [&](uint32_t t, uint32_t n, uint64_t& v0, uint64_t& v1) {
-      const int lv = 31 - __builtin_clz(n);
-      uint32_t off = n - (1u << lv);
-      if (!CHK(n >= 1u && n < 256u && ((long long)lv * h.T + t + off + 1) * NW <= h.sparse_words, 13)) { t = 0u; off = 0u; }
-      const uint64_t* sp = h.sparse + ((size_t)(n >= 1u && n < 256u ? lv : 0) * (size_t)h.T + t) * NW;
-      if (NW == 1) { v0 = sp[0] & sp[off]; v1 = 0ull; }
-      else {
-        const uint4 x = *reinterpret_cast<const uint4*>(sp), y = *reinterpret_cast<const uint4*>(sp + 2 * (size_t)off);
-        v0 = (((uint64_t)x.y << 32) | x.x) & (((uint64_t)y.y << 32) | y.x);
-        v1 = (((uint64_t)x.w << 32) | x.z) & (((uint64_t)y.w << 32) | y.z);
-      }
-    };
-    if (__ballot(p_n != 0u)) {
-      uint64_t s0 = ~0ull, s1 = ~0ull;
-      if (p_n != 0u) { range_and(p_t, p_n, s0, s1); fold(s0, s1, p_w0); }
-    }
-    // ---- left extension from the first seed (SPEC §3): as in nb_anchor_kernel ----
-    if (__ballot((fl & WF_REDO) == WF_LEXT)) {
-      const bool le = (fl & WF_REDO) == WF_LEXT;
-      int lm = 0; bool verify = false, solved = false;
-      if (le) {
-        const int s0 = ls_q > 32 ? ls_q - 32 : 0, na = ls_q - s0;
-        uint64_t sw; uint32_t sn; R.get32(s0, sw, sn);
-        const uint32_t t0 = ls_t > 32u ? ls_t - 32u : 0u; const int nb = (int)(ls_t - t0);
-        const U3 tw3 = *reinterpret_cast<const U3*>(h.text + (t0 >> 4));
-        const uint32_t sh = 2u * (t0 & 15u);
-        const uint64_t t01 = ((uint64_t)tw3.b << 32) | tw3.a;
-        const uint64_t tw = sh ? ((t01 >> sh) | ((uint64_t)tw3.c << (64u - sh))) : t01;
-        const uint64_t swt = sw << (2 * (32 - na)), twt = nb ? (tw << (2 * (32 - nb))) : ~swt;
-        const uint64_t df = swt ^ twt;
-        const uint64_t mm = (df | (df << 1)) & 0xAAAAAAAAAAAAAAAAull;
-        const int lead = mm ? (__builtin_clzll(mm) >> 1) : 32;
-        const uint32_t snt = na < 32 ? (sn << (32 - na)) : sn;
-        const int leadn = snt ? __builtin_clz(snt) : 32;
-        int cap = na < nb ? na : nb; cap = cap < ls_room ? cap : ls_room; cap = cap < 31 ? cap : 31;
-        lm = lead < leadn ? lead : leadn; lm = lm < cap ? lm : cap;
-        const int rr = ls_q - 1 - lm;
-        if (rr < 0 || leadn == lm) solved = true;
-        else verify = true;
-      }
-      if (__ballot(verify)) {
-        const int qy = ls_q - lm;
-        uint64_t w; uint32_t nn; R.get32(verify ? qy - 1 : 0, w, nn);
-        const uint32_t cb = (uint32_t)w & 3u;
-        const Look k = anchor_lookup<PLDS>(h, s_pilots, (w >> 2) & kmask, verify);
-        const uint32_t dd = k.e.x ^ k.want;
-        const bool mine = verify && dd < 4u && !(dd & 2u) && ((dd & 1u) == (k.o ? 1u : 0u));
-        if (verify && mine && !((k.e.y >> (4u + cb)) & 1u)) solved = true;
-      }
-      if (__ballot(solved && lm > 0)) {
-        uint64_t s0v = ~0ull, s1v = ~0ull;
-        if (solved && lm > 0) { range_and(ls_t - (uint32_t)lm, (uint32_t)lm, s0v, s1v); fold(s0v, s1v, lo); cov += lm; }
-      }
-      if (solved) fl &= ~WF_LEXT;
-    }
-    // ---- the other orientation: does any of ITS seed-scan positions hit? ----
-    {
-      Mask<NR> todo;
-      const uint64_t PAT = 0x9249249249249249ull;
-      const bool need = active && last >= 0 && !(fl & WF_REDO);
-#pragma unroll
-      for (int wi = 0; wi < NR; ++wi) {
-        const int res = ((last % 3 + 3) % 3 - (wi % 3) + 3) % 3;
-        uint64_t m = (PAT << res) & ~cover.w[wi];
-        const int top = last - wi * 64;
-        m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
-        todo.w[wi] = need ? m : 0ull;
-      }
-      while (__ballot(any_set<NR>(todo))) {
-        constexpr int U = 8;
-        LookKey kk[U]; bool vv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          int p = -1;
-#pragma unroll
-          for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
-          uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
-          vv[u] = p >= 0 && (nn & nkmask) == 0;
-          kk[u] = anchor_lookup_key<PLDS>(h, s_pilots, w & kmask, vv[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t dd = kk[u].d;
-          const bool found = vv[u] && dd < 4u;
-          const bool mine = found && !(dd & 2u) && ((dd & 1u) == (kk[u].o ? 1u : 0u));
-          if (found && !mine) fl |= WF_OPP;
-        }
-        if (fl & WF_OPP) {
-#pragma unroll
-          for (int wi = 0; wi < NR; ++wi) todo.w[wi] = 0;
-        }
-      }
-    }
-    if (MATE) {
-      if (active) {
-        MateRes mr; mr.info = (uint32_t)(cov & 0xFFFF) | ((rcf ? 1u : 0u) << 16) | (((fl & WF_REDO) ? MATE_REDO : MATE_OK) << 17); mr.lo = lo; mr.a0 = a0; mr.a1 = NW > 1 ? a1 : 0ull;
-        h.mate_out[r] = mr;
-      }
-    } else {
-      asm volatile("" ::: "memory");
-      const LaneTail& T = *tp;
-      const BatchArgs& a = T.a;
-      const int pmin = a.lens ? (int)a.pct_min[L] : a.pct_fixed;
-      int reason = NB_TOO_SHORT, score = 0, orient = 0, mates = 0;
-      uint32_t cls = NB_NO_CLASS;
-      bool to_redo = false, final_ = false, call = false;
-      if (active) {
-        if (fl & WF_REDO) to_redo = true;
-        else {
-          final_ = true;
-          if (a.out_cov) a.out_cov[r] = rcf ? ((uint64_t)(cov & 0xFFFF) << 16) : (uint64_t)(cov & 0xFFFF);
-          const int cheapS = cheap_reason_p(cov, pmin, a);
-          const uint32_t n = (uint32_t)__popcll(a0) + (NW > 1 ? (uint32_t)__popcll(a1) : 0u);
-          int rs = 0;
-          if (cheapS != 0) rs = cheapS;
-          else if (n == 0) rs = NB_EMPTY_EQCLASS;
-          else if (a.discard_multiple && n != 1) rs = NB_MULTIPLE_MATCH;
-          else if ((rcf && a.strand_filter == NB_STRAND_FIVEPRIME) || (!rcf && a.strand_filter == NB_STRAND_THREEPRIME)) rs = NB_STRAND;
-          if (rs) reason = rs;
-          else { score = cov; orient = rcf ? 1 : 0; mates = 1; reason = score < a.score_filter ? NB_SCORE_FILTER : NB_CALLED; call = reason == NB_CALLED; }
-        }
-      }
-      uint32_t leader = (uint32_t)lane, mult = call ? 1u : 0u;
-      bool lead = call;
-      {
-        uint64_t pendm = __ballot(call);
-        for (int it = 0; it < 6 && pendm; ++it) {
-          const int ld = __builtin_ctzll(pendm);
-          const uint32_t va_lo = __builtin_amdgcn_readlane((uint32_t)a0, ld), va_hi = __builtin_amdgcn_readlane((uint32_t)(a0 >> 32), ld);
-          const uint32_t vl = __builtin_amdgcn_readlane(lo, ld);
-          bool eq = call && (uint32_t)a0 == va_lo && (uint32_t)(a0 >> 32) == va_hi && lo == vl;
-          if (NW > 1) eq = eq && (uint32_t)a1 == (uint32_t)__builtin_amdgcn_readlane((uint32_t)a1, ld) && (uint32_t)(a1 >> 32) == (uint32_t)__builtin_amdgcn_readlane((uint32_t)(a1 >> 32), ld);
-          const uint64_t same = __ballot(eq) & pendm;
-          if ((same >> lane) & 1ull) { leader = (uint32_t)ld; lead = lane == ld; mult = lane == ld ? (uint32_t)__popcll(same) : 0u; }
-          pendm &= ~same;
-        }
-      }
-      if (lead && !CHK(lo < (uint32_t)T.W && (!(NW > 1 && a1) || lo + 1u < (uint32_t)T.W), 14)) lead = false;
-      cls = intern_lane2(T.ct, T.W, lead, lo, a0, NW > 1 ? a1 : 0ull);
-      cls = (uint32_t)__shfl((int)cls, (int)leader);
-      if (lead && cls != NB_NO_CLASS) {
-        const uint32_t slot = cls & (uint32_t)(CACHE - 1);
-        uint32_t tag = (h.dbg & 8) ? ~cls : s_ctag[slot];
-        if (tag == NB_NO_CLASS) { tag = atomicCAS(&s_ctag[slot], NB_NO_CLASS, cls); if (tag == NB_NO_CLASS) tag = cls; }
-        if (tag == cls) atomicAdd(&s_ccnt[slot], mult);
-        else atomicAdd(&T.ct.counts[cls], (unsigned long long)mult);
-      }
-      if (active && final_) {
-        atomicAdd(&s_reason[reason], 1u);
-        if (a.out_class) a.out_class[r] = (reason == NB_CALLED) ? cls : NB_NO_CLASS;
-        if (a.out_info) a.out_info[r] = (uint32_t)(score & 0xFFFF) | ((uint32_t)reason << 16) | ((uint32_t)orient << 24) | ((uint32_t)mates << 25);
-      }
-      const uint64_t mredo = __ballot(to_redo);
-      if (mredo) {
-        uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
-        b0 = __builtin_amdgcn_readfirstlane(b0);
-        if (to_redo) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & lt)] = r;
-      }
-    }
-  }
-  __syncthreads();
-  if (!MATE)
-    for (int i = threadIdx.x; i < CACHE; i += blockDim.x)
-      if (s_ctag[i] != NB_NO_CLASS && s_ccnt[i]) atomicAdd(&tp->ct.counts[s_ctag[i]], (unsigned long long)s_ccnt[i]);
-  if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
-}
-
 // SPEC §4 for paired templates from the two mates' raw alignments (MateRes): one pair per lane. A mate has ONE orientation with hits (the
 // other is NONE: coverage 0, NO_HIT) or none at all, so the four alignments map(r1), map(rc(r1)), map(r2), map(rc(r2)) are all known; they
 // are checked and combined exactly as nb_align_general_kernel does (evaluate_alignment, combine_mates). Pairs with a mate the anchor
@@ -1404,37 +821,6 @@ static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_
   AnchorHead h = h_in;                                               // scan-list segment of a workgroup: as many entries as it has reads
   h.scan_seg = ((h.n + blocks * waves * 64 - 1) / (blocks * waves * 64)) * waves * 64;
   if (blocks * h.scan_seg > c->scan_list_cap || blocks > c->scan_counts_cap) { set_error("launch_anchor: scan list too small"); return NB_ERR_INVALID; }
-  // Pipelined form (default): walk kernel with per-lane refill + finish kernel; needs the per-wave FIFOs and 48..80 B of walk result per read.
-  // If that memory is not to be had, the lock-step kernel below runs instead (same results).
-  c->anchor_pipe_ran = false;
-  { const char* e = std::getenv("NB_ANCHOR_PIPE");
-    if (!(e && e[0] == '0')) {
-      const size_t ring_bytes = (size_t)blocks * (size_t)waves * (size_t)PIPE_RING * (size_t)PipeShape<NR>::SLOT_DW * 4u;
-      const size_t wres_bytes = (size_t)h.n * (size_t)WResShape<NR, NW>::DW * 4u;
-      bool ok = true;
-      if (c->ring_bytes < ring_bytes) {
-        (void)hipFree(c->d_ring); c->d_ring = nullptr; c->ring_bytes = 0;
-        if (hipMalloc((void**)&c->d_ring, ring_bytes) == hipSuccess) c->ring_bytes = ring_bytes; else { (void)hipGetLastError(); ok = false; }
-      }
-      if (ok && c->wres_bytes < wres_bytes) {
-        (void)hipFree(c->d_wres); c->d_wres = nullptr; c->wres_bytes = 0;
-        if (hipMalloc((void**)&c->d_wres, wres_bytes) == hipSuccess) c->wres_bytes = wres_bytes; else { (void)hipGetLastError(); ok = false; }
-      }
-      if (ok) {
-        h.ring = c->d_ring; h.wres = c->d_wres;
-        NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_walk_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANCHOR_LDS_BUDGET));
-        NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_finish_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANCHOR_LDS_BUDGET));
-        NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        hipLaunchKernelGGL((nb_anchor_walk_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
-        NB_HIP(hipGetLastError());
-        hipLaunchKernelGGL((nb_anchor_finish_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
-        NB_HIP(hipGetLastError());
-        hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
-        NB_HIP(hipGetLastError());
-        c->anchor_pipe_ran = true; c->anchor_retry_ran = false;
-        return NB_OK;
-      }
-    } }
   int retry_lanes = 6;                                               // (c2: 8.7 % of the reads walk for more than 12 rounds, waves for 18)
   if (const char* e = std::getenv("NB_ANCHOR_RETRY_LANES")) { const int v = std::atoi(e); if (v >= 0 && v < 64) retry_lanes = v; }
   long long retry_min = 64LL * 64 * waves;                           // (small batches: nothing to gain from a second launch)
@@ -1496,7 +882,7 @@ static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads
   return AnchorHead{c->d_atable, c->d_akeys, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
                     (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out,
-                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
+                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0};
 }
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {

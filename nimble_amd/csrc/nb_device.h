@@ -380,7 +380,6 @@ struct nb_ctx {
   void* d_lane_tail = nullptr;     // LaneTail of the current batch (nb_lane.hip)
   nb::PHEntry* d_ph_table = nullptr; uint8_t* d_ph_pilots = nullptr; nb::PHash ph{}; bool has_ph = false;   // perfect-hash table of the lane kernels
   uint32_t* d_retry_list = nullptr; uint32_t* d_retry_counts = nullptr; int64_t retry_cap = 0;   // stragglers of the anchor kernel's first pass (nb_anchor.hip)
-  uint32_t* d_ring = nullptr; size_t ring_bytes = 0; uint32_t* d_wres = nullptr; size_t wres_bytes = 0; bool anchor_pipe_ran = false;   // pipelined anchor kernels: per-wave FIFOs, per-read walk results
   bool anchor_retry_ran = false;   // the last launch_anchor / launch_anchor_pairs ran the second pass (reported in last_kernels)
   uint32_t* d_akeys = nullptr;     // key words of d_atable alone (nb_internal.h, akeys)
   nb::AEntry* d_atable = nullptr; uint32_t* d_text = nullptr; uint64_t* d_sparse = nullptr; long long text_len = 0; bool has_anchor = false; int anchor_nw = 1;   // anchor structures (nb_anchor.hip)

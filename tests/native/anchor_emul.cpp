@@ -32,34 +32,8 @@ using namespace nb;
 template <class T> static T rd(FILE* f) { T v; if (std::fread(&v, sizeof v, 1, f) != 1) { std::fprintf(stderr, "short input\n"); std::exit(2); } return v; }
 
 static unsigned long long g_retried = 0;
-// pipelined form (nb_anchor_walk_kernel + nb_anchor_finish_kernel): NB_EMUL_PIPE=<g> runs the walk kernel with one wave per g emulated
-// batches, so that its single lane produces, binds, walks and refills through a FIFO that wraps around (g * 1 reads per wave > PIPE_RING for
-// large g); the finish kernel and the scan kernel run one batch per block as before.
-template <int NR, int NW>
-static void run_pipe(const AnchorHead& h_in, const LaneTail* tail, long long blocks, long long group) {
-  AnchorHead h = h_in;
-  const long long wblocks = (blocks + group - 1) / group;
-  std::vector<uint32_t> ring((size_t)wblocks * PIPE_RING * PipeShape<NR>::SLOT_DW, 0xDEADBEEFu), wres((size_t)h.n * WResShape<NR, NW>::DW, 0xDEADBEEFu);
-  h.ring = ring.data(); h.wres = wres.data(); h.scan_seg = 64 * group;
-  blockDim = dim3(64); threadIdx = dim3(0);
-  gridDim = dim3((unsigned)wblocks);
-  for (long long b = 0; b < wblocks; ++b) { blockIdx = dim3((unsigned)b); nb_anchor_walk_kernel<NR, NW, false, false>(h, tail); }
-  gridDim = dim3((unsigned)blocks);
-  for (long long b = 0; b < blocks; ++b) { blockIdx = dim3((unsigned)b); nb_anchor_finish_kernel<NR, NW, false, false>(h, tail); }
-  // the scan kernel maps entry 64 w + lane of a segment in lane `lane`: with one lane per wave, one entry per block (spread out here)
-  std::vector<uint32_t> entries;
-  for (long long b = 0; b < wblocks; ++b) for (uint32_t j = 0; j < h.scan_counts[b]; ++j) entries.push_back(tail->ll.rc_list[(size_t)b * (size_t)h.scan_seg + j]);
-  if (entries.size() > (size_t)blocks) { std::fprintf(stderr, "more scan entries than reads\n"); std::exit(7); }
-  for (long long b = 0; b < blocks; ++b) h.scan_counts[b] = 0;
-  for (size_t e = 0; e < entries.size(); ++e) { tail->ll.rc_list[e * 64] = entries[e]; h.scan_counts[e] = 1; }
-  h.scan_seg = 64;
-  gridDim = dim3((unsigned)blocks);
-  for (long long b = 0; b < blocks; ++b) { blockIdx = dim3((unsigned)b); nb_anchor_scan_kernel<NR, false, false>(h, tail); }
-}
-
 template <int NR, int NW>
 static void run_kernels(const AnchorHead& h_in, const LaneTail* tail, long long blocks, std::vector<uint32_t>* retry) {
-  if (const char* e = std::getenv("NB_EMUL_PIPE")) { const long long g = std::atoll(e); run_pipe<NR, NW>(h_in, tail, blocks, g < 1 ? 1 : g); return; }
   // one wave per workgroup, one lane per wave: block b maps read 64 * b, then (last pass) scans its own segment of the scan list.
   // retry: every other read is handed to the second pass of nb_anchor_kernel after its first round (retry_lanes = 1 with one lane per wave,
   // switched per block), which maps its segment of the retry list from scratch.
@@ -123,7 +97,7 @@ int main(int argc, char** argv) {
   LaneTail tail{ct, a, ll, W};
   std::vector<uint32_t> scan_counts((size_t)n_reads, 0);
   AnchorHead h{ix->atable.data(), ix->akeys.data(), ix->ph_pilots.data(), ix->ph, k, ix->text.data(), ix->sparse.data(), (long long)ix->text_len, reads.data(), lens.data(), max_len, stride, nwb,
-               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
+               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0};
   std::vector<uint32_t> retry_list((size_t)n_reads * 64 + 64, 0);
   std::vector<uint32_t>* retry = std::getenv("NB_EMUL_RETRY") ? &retry_list : nullptr;
   const int positions = max_len - k + 1, nr = positions < 1 ? 1 : (positions + 63) / 64;

@@ -41,27 +41,20 @@ def _run(emul, tmp_path, strs, k, reads, max_len, cfg, max_redo_frac):
         f.write(np.ascontiguousarray(lens, dtype=np.uint16).tobytes())
         f.write(struct.pack("<iiiid", cfg.score_threshold, cfg.score_filter, cfg.discard_multiple_matches, cfg.strand_filter, cfg.score_percent))
     ora = oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=4)
-    # the lock-step kernel twice: one pass of nb_anchor_kernel, and with every other read handed to its second pass (the stragglers' retry list)
+    # twice: one pass of nb_anchor_kernel, and with every other read handed to its second pass (the stragglers' retry list)
     for retry in (True, False):
         got, log = _emulate(emul, inp, out, retry)
         _compare(got, ora, max_redo_frac, log)
         retried = int(log.split("retried ")[1].split(",")[0])
         assert (retried > 0) == (retry and len(reads) > 50), log
-    # the pipelined kernels (walk with per-lane refill + finish): one read per wave, and 200 reads per wave (its FIFO of 128 slots wraps around)
-    for group in (1, 200):
-        got, log = _emulate(emul, inp, out, False, pipe=group)
-        _compare(got, ora, max_redo_frac, log)
     return got, ora, log
 
 
-def _emulate(emul, inp, out, retry, pipe=0):
+def _emulate(emul, inp, out, retry):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     env.pop("NB_EMUL_RETRY", None)
-    env.pop("NB_EMUL_PIPE", None)
     if retry:
         env["NB_EMUL_RETRY"] = "1"
-    if pipe:
-        env["NB_EMUL_PIPE"] = str(pipe)
     r = subprocess.run([emul, inp, out], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     raw = open(out, "rb").read()

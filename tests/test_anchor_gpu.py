@@ -22,7 +22,7 @@ def _check(strs, k, reads, max_len, what, cfg=None, expect_anchor=True):
     cfg = cfg or engine.make_config(k=k)
     words, lens = engine.pack_reads(reads, max_len)
     gpu = run_gpu(engine.Index(strs, k), cfg, words, lens, max_len)
-    assert any(name.startswith("nb_anchor_") for name in gpu["kernels"]) == expect_anchor, gpu["kernels"]
+    assert any(name.startswith("nb_anchor_kernel") for name in gpu["kernels"]) == expect_anchor, gpu["kernels"]
     ora = oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=8)
     assert_same(gpu, ora, what)
     return ora
@@ -224,7 +224,6 @@ def test_straggler_retry_pass(built, monkeypatch, lanes, rounds):
     Ns) and paired, against the oracle."""
     from oracle import oracle
     from tests.test_general_gpu import synth_pairs
-    monkeypatch.setenv("NB_ANCHOR_PIPE", "0")                       # (the lock-step form of the kernel: the pipelined form has no second pass)
     monkeypatch.setenv("NB_ANCHOR_RETRY_MIN", "0"); monkeypatch.setenv("NB_ANCHOR_RETRY_LANES", str(lanes)); monkeypatch.setenv("NB_ANCHOR_RETRY_ROUNDS", str(rounds))
     _, seqs, strs, _ = library_strings(20, 50)
     codes = synth.synth_reads(seqs, 30000, 150, seed=33, err=0.02, n_rate=0.003)
