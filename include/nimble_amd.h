@@ -113,6 +113,14 @@ int32_t nb_index_stats(const nb_index* index, nb_index_stats_t* out);
  * (words_per_row u64), 0 if absent, <0 on error. Used by index-parity tests. */
 int32_t nb_index_query(const nb_index* index, const char* kmer_ascii, uint8_t* lext, uint8_t* rext, uint8_t* r_internal,
                        uint8_t* l_internal, uint64_t* colour_bits);
+
+/* host query of the presence filter of the scan kernel (csrc/nb_internal.h) for a sequence of len >= m bases AS GIVEN (no canonical
+ * form, no reverse complement): 1 = every m-mer of it passes both stages, i.e. a k-mer containing them may be in the library (the kernel
+ * then takes the exact lookup); 0 = some m-mer is certainly in no k-mer of the library on either strand; 2 = the index carries no
+ * filter (no anchor structures); len = 0 only reports the parameters. m_out = the filter's m, lds_stage_out = 1 if the LDS stage was built. An m-mer with a base other than
+ * ACGT counts as passing. No false negatives: nb_index_query fails if an m-mer of a k-mer of the table is rejected. Test / inspection
+ * helper; the reference has no counterpart (its index lives inside the Rust binary, /root/reference/nimble/__main__.py:195). */
+int32_t nb_index_filter_maybe(const nb_index* index, const char* seq_ascii, int32_t len, int32_t* m_out, int32_t* lds_stage_out);
 /* host query of the anchor structures (csrc/nb_internal.h, AEntry) for one stranded k-mer: returns 1 and fills the text position of its
  * anchor occurrence, `room` (steps the walk may take along the text from there) and, in colour_and (words_per_row u64, original sequence
  * numbering), the AND of the classes of the k-mers at text positions [tpos, tpos + min(run, room)]; 2 (tpos and room only) if the anchor

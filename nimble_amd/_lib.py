@@ -55,6 +55,7 @@ SIGNATURES = {
     "nb_index_destroy": (ct.c_int32, [ct.c_void_p]),
     "nb_index_stats": (ct.c_int32, [ct.c_void_p, ct.POINTER(NbIndexStats)]),
     "nb_index_query": (ct.c_int32, [ct.c_void_p, ct.c_char_p, c_u8p, c_u8p, c_u8p, c_u8p, c_u64p]),
+    "nb_index_filter_maybe": (ct.c_int32, [ct.c_void_p, ct.c_char_p, ct.c_int32, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     "nb_classes_copy_device": (ct.c_int32, [ct.c_void_p, ct.c_int64, ct.c_void_p, ct.c_void_p, ct.c_void_p]),
     "nb_rows_to_external": (ct.c_int32, [ct.c_void_p, c_u64p, ct.c_int64, c_u64p]),
     "nb_index_anchor_query": (ct.c_int32, [ct.c_void_p, ct.c_char_p, ct.c_int32, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int32), c_u64p]),

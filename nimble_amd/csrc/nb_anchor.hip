@@ -57,6 +57,8 @@ struct AnchorHead {
   // the scan list) and the wave moves on. Second pass (retry_in set, same grid): workgroup b maps its own segment, reads from scratch, in waves
   // that hold nothing but long walks.
   uint32_t* retry_out; const uint32_t* retry_in; uint32_t* retry_counts; int retry_lanes, retry_rounds;
+  const uint32_t* pfilter; uint32_t pf_wbits;        // presence filter over the oriented k-mers of the table (nb_internal.h): 2^pf_wbits words
+  const uint32_t* lfilter;                           // its LDS-sized first stage (2^20 bits), or null (library too large for it to discriminate)
 };
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
@@ -154,6 +156,12 @@ __device__ __forceinline__ LookKey anchor_lookup_key(const AnchorHead& h, const 
   if (!CHK(slot < h.ph.n_slots, 11)) slot = 0u;
   k.d = h.keys[slot] ^ pr.want;
   return k;
+}
+
+// presence filter (nb_internal.h): false = the k-mer is in the table on neither strand; true = maybe (the exact lookup decides)
+__device__ __forceinline__ bool filter_maybe(const AnchorHead& h, uint64_t x, bool valid) {
+  const uint32_t hh = pf_hash(x), m = pf_mask(hh);
+  return valid && (h.pfilter[valid ? pf_word(hh, h.pf_wbits) : 0u] & m) == m;
 }
 
 template <int NR, int NW, bool PLDS, bool MATE>
@@ -440,6 +448,9 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
         todo.w[wi] = need ? m : 0ull;
       }
+      // (tried: the presence filter of the scan kernel in front of these lookups. c2 3.52 ms against 3.21: the positions are few and per
+      //  lane, so the filter saves no request — one 4-byte load either way — and the second loop for the positions that pass costs more
+      //  than the shorter hash saves; profiles/r03_tuning_notes.md)
       while (__ballot(any_set<NR>(todo))) {
         constexpr int U = 8;
         LookKey kk[U]; bool vv[U];
@@ -582,73 +593,145 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
   if (threadIdx.x < NB_NUM_REASONS && s_reason[threadIdx.x]) atomicAdd(&tp->ct.reasons[threadIdx.x], (unsigned long long)s_reason[threadIdx.x]);
 }
 
-// The reads none of whose three probes was in the table (ll.rc_list): every seed-scan position of BOTH orientations is looked up, all lanes
-// in lock-step, four lookups in flight per lane. No k-mer found at all: NO_HIT in both orientations, final. Anything found: redo list.
-template <int NR, bool PLDS, bool MATE>
+// The reads none of whose three probes was in the table (ll.rc_list) — for a library of a few gene families against whole-transcriptome
+// reads, nearly all of the input: every seed-scan position of BOTH orientations must be shown absent (88 positions of a 150-bp read at
+// k = 20). An exact lookup per position made this kernel run at the rate at which the L2s accept requests (~100 four-byte requests per read:
+// 210 G requests/s, profiles/r03_tuning_notes.md). Here (presence filter, nb_internal.h) the read is cut into tiles of S k-mer positions; ONE
+// m-mer per tile (m = k + 1 - S: it lies inside every k-mer of the tile) goes through
+//   LDS    the one-bit-per-slot table of 2^20 bits over the library's oriented m-mers, copied into LDS by every workgroup (when the
+//          library is small enough for it to discriminate: HostIndex::lfilter), then, if it passes,
+//   L2     the blocked Bloom filter in global memory (one 4-byte load),
+// and only the seed-scan positions of tiles that pass both (< 1 % for a foreign read) take the exact lookup (two-level perfect hash, its
+// first level read from L2 here: LDS holds the filter). The record stays in REGISTERS: tile positions are the same for all lanes, so an
+// m-mer is a funnel shift of three register dwords by a constant, sixteen bases per block, fully unrolled.
+// Nothing found = NO_HIT in both orientations, final; anything found = redo list (wave-per-read kernel).
+constexpr int SCAN_LF_WORDS = 1 << (LF_BITS_LOG2 - 5);       // 2^20 bits = 128 KB of LDS
+template <int NR, int S, bool MATE>
 __global__ __launch_bounds__(1024) void nb_anchor_scan_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_nohit;
-  uint8_t* s_pilots = s_dyn;
+  uint32_t* s_lf = reinterpret_cast<uint32_t*>(s_dyn);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wpb = (int)(blockDim.x >> 6);
-  uint32_t* rec = reinterpret_cast<uint32_t*>(s_dyn + h.pilot_lds_bytes) + (size_t)wave * h.rec_dwords * 64;
   const LaneTail& T = *tp;
   const long long count = (long long)h.scan_counts[blockIdx.x];                // this workgroup's segment of the scan list (written by the same block index)
   const uint32_t* __restrict__ seg = T.ll.rc_list + (size_t)blockIdx.x * (size_t)h.scan_seg;
+  const bool lds_stage = h.lfilter != nullptr;
   if (threadIdx.x == 0) s_nohit = 0;
-  if (PLDS && count > 0)
-    for (int i = threadIdx.x * 16; i < h.pilot_lds_bytes; i += blockDim.x * 16)
-      *reinterpret_cast<uint4*>(s_pilots + i) = *reinterpret_cast<const uint4*>(h.pilots + i);
+  if (lds_stage && count > 0)
+    for (int i = threadIdx.x * 4; i < SCAN_LF_WORDS; i += blockDim.x * 4)
+      *reinterpret_cast<uint4*>(s_lf + i) = *reinterpret_cast<const uint4*>(h.lfilter + i);
   __syncthreads();
-  const int K = h.K;
-  const uint64_t kmask = (1ull << (2 * K)) - 1;
-  const uint32_t nkmask = (1u << K) - 1u;
-  const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1;
+  const int K = h.K, M = K + 1 - S;                                             // (S = the index's pf_s: launch_anchor_t picks the instantiation)
+  const uint64_t kmask = (1ull << (2 * K)) - 1, mmask = (1ull << (2 * M)) - 1;
+  const uint32_t nkmask = (1u << K) - 1u, nmmask = (1u << M) - 1u;
+  const int nwb = h.nwb, nwn = (h.nwb + 1) >> 1, nbd = 2 * nwb, nd = 2 * nwn;
+  const uint64_t lt = (1ull << lane) - 1;
+  constexpr int MAXNWB = 2 * NR + 1, MAXNWN = NR + 1, MAXBLK = 4 * NR + 1;      // (at most 64 NR positions; the last tile's m-mer may start up to S - 1 bases later)
+  constexpr int TPB = 16 / S;                                                   // tiles per block of sixteen bases
   for (long long base = (long long)wave * 64; base < count; base += (long long)wpb * 64) {
     const long long idx = base + lane;
     const bool active = idx < count;
     const uint32_t r = active ? seg[idx] : 0u;
     int L = 0;
     if (active) { L = h.lens ? (int)h.lens[r] : h.max_len; if (L > h.max_len) L = h.max_len; }
-    Rec R{rec + lane, 2 * nwb, 2 * nwn, L};
-    {
-      const uint64_t* __restrict__ rp = h.reads + (size_t)r * h.stride;
-      for (int j = 0; j < nwb + nwn; ++j) {
-        const uint64_t w = active ? rp[j] : 0ull;
-        R.at(2 * j) = (uint32_t)w; R.at(2 * j + 1) = (uint32_t)(w >> 32);
-      }
-      R.at(2 * (nwb + nwn)) = 0u; R.at(2 * (nwb + nwn) + 1) = 0u;
-    }
-    const int last = L - K;
-    Mask<NR> todo;
-    const uint64_t PAT = 0x9249249249249249ull;
+    const uint64_t* __restrict__ rp = h.reads + (size_t)r * h.stride;
+    uint64_t wb[MAXNWB + 2], wn[MAXNWN + 2];
 #pragma unroll
-    for (int wi = 0; wi < NR; ++wi) {                                       // p % 3 == 0 (forward seed scan) or p % 3 == last % 3 (the other orientation's)
-      const int r0 = (3 - (wi % 3)) % 3, r1 = ((last % 3 + 3) % 3 - (wi % 3) + 3) % 3;
-      uint64_t m = (PAT << r0) | (PAT << r1);
-      const int top = last - wi * 64;
-      m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
-      todo.w[wi] = (active && last >= 0) ? m : 0ull;
+    for (int j = 0; j < MAXNWB + 2; ++j) wb[j] = (active && j < nwb) ? rp[j] : 0ull;
+#pragma unroll
+    for (int j = 0; j < MAXNWN + 2; ++j) wn[j] = (active && j < nwn) ? rp[nwb + j] : 0ull;
+    const int last = L - K;
+    const bool act = active && last >= 0;
+    // the seed-scan positions: p % 3 == 0 (forward) or p % 3 == last % 3 (the other orientation's), p <= last
+    Mask<NR> latt;
+    {
+      const uint64_t PAT = 0x9249249249249249ull;
+#pragma unroll
+      for (int wi = 0; wi < NR; ++wi) {
+        const int r0 = (3 - (wi % 3)) % 3, r1 = ((last % 3 + 3) % 3 - (wi % 3) + 3) % 3;
+        uint64_t m = (PAT << r0) | (PAT << r1);
+        const int top = last - wi * 64;
+        m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
+        latt.w[wi] = act ? m : 0ull;
+      }
     }
+    Mask<NR> cand;                                                              // positions of the tiles that passed both filter stages
+#pragma unroll
+    for (int wi = 0; wi < NR; ++wi) cand.w[wi] = 0;
+    const int nblk = h.max_len >= K ? (h.max_len - K + S - 1) / 16 + 1 : 0;     // blocks that hold a tile's m-mer start
+    // chunks of blocks (~10-16 tiles): first every LDS word of the chunk, then every filter word, then the verdicts — straight-line code
+    // with unconditional loads (an index that does not matter is 0), so that a chunk costs two round trips whatever it holds
+    constexpr int CH = S >= 16 ? MAXBLK : (S == 8 ? 5 : (S == 4 ? 3 : (S == 2 ? 2 : 1))), NT = CH * TPB;
+#pragma unroll
+    for (int c0 = 0; c0 < MAXBLK; c0 += CH) {
+      if (c0 < nblk && __ballot(act && 16 * c0 - (S - 1) <= last)) {
+        uint32_t hh[NT], li[NT], lw[NT]; uint32_t needm = 0, cleanm = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int b = c0 + t / TPB, j = t % TPB;
+          hh[t] = 0u; li[t] = 0u; lw[t] = ~0u;
+          if (b < MAXBLK) {
+            const uint32_t d0 = (uint32_t)(wb[b >> 1] >> (32 * (b & 1))), d1 = (uint32_t)(wb[(b + 1) >> 1] >> (32 * ((b + 1) & 1))), d2 = (uint32_t)(wb[(b + 2) >> 1] >> (32 * ((b + 2) & 1)));
+            const uint64_t lo64 = ((uint64_t)d1 << 32) | d0, hi64 = ((uint64_t)d2 << 32) | d1;
+            const uint64_t nn64 = (b & 2) ? ((wn[b >> 2] >> 32) | (wn[(b >> 2) + 1] << 32)) : wn[b >> 2];       // N bits from position 32 (b >> 1)
+            const int i = S * j + S - 1, q = 16 * b + i;                        // the tile's m-mer starts at base q and clears the k-mer positions [q - (S - 1), q]
+            const uint32_t sh = 2u * (uint32_t)i;
+            const uint64_t x = ((((uint64_t)(uint32_t)(hi64 >> sh)) << 32) | (uint32_t)(lo64 >> sh)) & mmask;
+            needm |= (act && b < nblk && q - (S - 1) <= last) ? (1u << t) : 0u;
+            cleanm |= (((uint32_t)(nn64 >> (16 * (b & 1) + i)) & nmmask) == 0) ? (1u << t) : 0u;                // (an N inside the m-mer: nothing is known about the tile)
+            hh[t] = pf_hash(x); li[t] = lf_index(x);
+          }
+        }
+        if (lds_stage) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) lw[t] = s_lf[li[t] >> 5];
+        }
+        uint32_t okm = 0;                                                      // tiles still undecided after the LDS stage
+#pragma unroll
+        for (int t = 0; t < NT; ++t) okm |= (((lw[t] >> (li[t] & 31u)) & 1u) || !((cleanm >> t) & 1u)) ? (1u << t) : 0u;
+        okm &= needm;
+        uint32_t fw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fw[t] = h.pfilter[pf_word(hh[t], h.pf_wbits) & (((okm & cleanm) >> t) & 1u ? ~0u : 0u)];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int b = c0 + t / TPB, j = t % TPB, p0 = 16 * b + S * j;        // first position of the tile (a multiple of S: a tile never straddles a mask word)
+          const uint32_t fm = pf_mask(hh[t]);
+          const bool pass = ((okm >> t) & 1u) && (!((cleanm >> t) & 1u) || (fw[t] & fm) == fm);
+          if (p0 < 64 * NR) cand.w[p0 >> 6] |= pass ? (((1ull << S) - 1) << (p0 & 63)) : 0ull;
+        }
+      }
+    }
+#pragma unroll
+    for (int wi = 0; wi < NR; ++wi) cand.w[wi] &= latt.w[wi];
+    // exact lookups for the seed-scan positions of the tiles that passed (windows straight from the record in global memory: they are rare)
     bool hit = false;
-    while (__ballot(any_set<NR>(todo))) {
-      constexpr int U = 8;
+    const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp);
+    while (__ballot(any_set<NR>(cand))) {
+      constexpr int U = 6;                                                      // (a tile that passed by chance has ~S / 3 * 2 seed-scan positions: one round trip for all of them)
       LookKey kk[U]; bool vv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int p = -1;
 #pragma unroll
-        for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
-        uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
+        for (int wi = 0; wi < NR; ++wi) if (p < 0 && cand.w[wi]) { p = wi * 64 + __builtin_ctzll(cand.w[wi]); cand.w[wi] &= cand.w[wi] - 1; }
+        const int q = p < 0 ? 0 : p, j = q >> 4; const uint32_t sh = 2u * ((uint32_t)q & 15u);
+        const U3 t3 = *reinterpret_cast<const U3*>(rp32 + (CHK(j + 2 < nbd + nd, 15) ? j : 0));            // (dwords j .. j + 2 <= nbd + 1 < nbd + nd)
+        const uint64_t lo = ((uint64_t)t3.b << 32) | t3.a;
+        const uint64_t w = sh ? ((lo >> sh) | ((uint64_t)t3.c << (64u - sh))) : lo;
+        const int an = q >> 5;
+        const uint32_t n0 = rp32[nbd + (an < nd ? an : 0)], n1 = an + 1 < nd ? rp32[nbd + an + 1] : 0u;
+        const uint32_t nn = (uint32_t)((((uint64_t)n1 << 32) | n0) >> ((uint32_t)q & 31u));
         vv[u] = p >= 0 && (nn & nkmask) == 0;
-        kk[u] = anchor_lookup_key<PLDS>(h, s_pilots, w & kmask, vv[u]);
+        kk[u] = anchor_lookup_key<false>(h, nullptr, w & kmask, vv[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) hit = hit || (vv[u] && kk[u].d < 4u);
       if (hit) {
 #pragma unroll
-        for (int wi = 0; wi < NR; ++wi) todo.w[wi] = 0;
+        for (int wi = 0; wi < NR; ++wi) cand.w[wi] = 0;
       }
     }
     if (MATE) {
@@ -656,17 +739,18 @@ __global__ __launch_bounds__(1024) void nb_anchor_scan_kernel(AnchorHead h, cons
     } else {
       const BatchArgs& a = T.a;
       if (active && !hit) {
-        atomicAdd(&s_nohit, 1u);
         if (a.out_class) a.out_class[r] = NB_NO_CLASS;
         if (a.out_info) a.out_info[r] = (uint32_t)NB_NO_HIT << 16;
         if (a.out_cov) a.out_cov[r] = 0ull;
       }
+      const uint64_t mno = __ballot(active && !hit);
+      if (mno && lane == 0) atomicAdd(&s_nohit, (unsigned int)__popcll(mno));
       const uint64_t mredo = __ballot(active && hit);
       if (mredo) {
         uint32_t b0 = 0;
         if (lane == 0) b0 = atomicAdd(&T.ll.counters[1], (uint32_t)__popcll(mredo));
         b0 = __builtin_amdgcn_readfirstlane(b0);
-        if (active && hit) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & ((1ull << lane) - 1))] = r;
+        if (active && hit) T.ll.redo_list[b0 + (uint32_t)__popcll(mredo & lt)] = r;
       }
     }
   }
@@ -809,6 +893,24 @@ static int64_t anchor_lds_bytes(const nb_ctx* c, int max_len, int* waves_per_blo
   return pil + (int64_t)w * rec;
 }
 
+template <int NR, int S, bool MATE>
+static int launch_scan_t(const AnchorHead& h, const LaneTail* d_tail, long long blocks, int waves, hipStream_t s) {
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR, S, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, S, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)(h.lfilter ? SCAN_LF_WORDS * 4 : 0), s, h, d_tail);   // (same grid: block b scans block b's segment)
+  NB_HIP(hipGetLastError());
+  return NB_OK;
+}
+template <int NR, bool MATE>
+static int launch_scan_s(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, long long blocks, int waves, hipStream_t s) {
+  switch (c->pf_s) {                                                  // stride of the presence filter's tiles (pf_stride(k), nb_internal.h)
+    case 16: return launch_scan_t<NR, 16, MATE>(h, d_tail, blocks, waves, s);
+    case 8: return launch_scan_t<NR, 8, MATE>(h, d_tail, blocks, waves, s);
+    case 4: return launch_scan_t<NR, 4, MATE>(h, d_tail, blocks, waves, s);
+    case 2: return launch_scan_t<NR, 2, MATE>(h, d_tail, blocks, waves, s);
+    default: return launch_scan_t<NR, 1, MATE>(h, d_tail, blocks, waves, s);
+  }
+}
+
 template <int NR, int NW, bool PLDS, bool MATE>
 static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
   NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANCHOR_LDS_BUDGET));
@@ -846,9 +948,7 @@ static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_
     NB_HIP(hipGetLastError());
     h.retry_in = nullptr;
   }
-  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_scan_kernel<NR, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-  hipLaunchKernelGGL((nb_anchor_scan_kernel<NR, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);   // (same grid: block b scans block b's segment)
-  NB_HIP(hipGetLastError());
+  return launch_scan_s<NR, MATE>(c, h, d_tail, blocks, waves, s);
   return NB_OK;
 }
 template <int NR, bool MATE>
@@ -882,7 +982,7 @@ static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads
   return AnchorHead{c->d_atable, c->d_akeys, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
                     (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out,
-                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0};
+                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0, c->d_pfilter, c->pf_wbits, c->d_lfilter};
 }
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {

@@ -539,7 +539,27 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       for (size_t i = 0; i < ix->atable.size(); ++i) ix->akeys[i] = ix->atable[i].key;
       lap("anchor entries");
       ix->has_anchor = fits;
-      if (!fits) { std::vector<uint32_t>().swap(ix->akeys); std::vector<AEntry>().swap(ix->atable); std::vector<uint64_t>().swap(ix->sparse); std::vector<uint32_t>().swap(ix->text); }
+      if (fits) {                                                      // presence filter (nb_internal.h): the m-mers of both orientations of every k-mer of the table
+        ix->pf_s = pf_stride(k); ix->pf_m = k + 1 - ix->pf_s;
+        ix->pf_wbits = pf_words_log2(n_canon);
+        ix->pfilter.assign((size_t)1 << ix->pf_wbits, 0u);
+        ix->lfilter.assign((size_t)1 << (LF_BITS_LOG2 - 5), 0u);
+        const uint64_t mmask = (1ull << (2 * ix->pf_m)) - 1;
+        for (int64_t i = 0; i < n_canon; ++i) {
+          const uint64_t c = canons[(size_t)i].key, both[2] = {c, rc_kmer_host(c, k)};
+          for (int o = 0; o < 2; ++o) for (int sh = 0; sh < ix->pf_s; ++sh) {
+              const uint64_t mm = (both[o] >> (2 * sh)) & mmask;
+              const uint32_t h0 = pf_hash(mm), li = lf_index(mm);
+              ix->pfilter[pf_word(h0, ix->pf_wbits)] |= pf_mask(h0);
+              ix->lfilter[li >> 5] |= 1u << (li & 31u);
+            }
+        }
+        { int64_t set = 0; for (uint32_t w : ix->lfilter) set += __builtin_popcount(w);
+          if (dbg) std::fprintf(stderr, "[nb_index] presence filter: m = %d, stride %d, %u KB, LDS stage %.1f %% full\n", ix->pf_m, ix->pf_s, (unsigned)(ix->pfilter.size() * 4 / 1024), 100.0 * (double)set / (double)((int64_t)1 << LF_BITS_LOG2));
+          if ((double)set > LF_MAX_FILL * (double)((int64_t)1 << LF_BITS_LOG2)) std::vector<uint32_t>().swap(ix->lfilter); }
+        lap("presence filter");
+      }
+      if (!fits) { std::vector<uint32_t>().swap(ix->lfilter); std::vector<uint32_t>().swap(ix->pfilter); std::vector<uint32_t>().swap(ix->akeys); std::vector<AEntry>().swap(ix->atable); std::vector<uint64_t>().swap(ix->sparse); std::vector<uint32_t>().swap(ix->text); }
     }
   }
   ix->n_canonical = n_canon;

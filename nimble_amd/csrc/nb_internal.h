@@ -177,6 +177,35 @@ constexpr int64_t ANCHOR_LOOKAHEAD = 64;                // text k-mers ahead tha
 constexpr int64_t ANCHOR_MAX_SPARSE_BYTES = 8ll << 30;  // 8 levels x 8 (16) bytes per library base: libraries up to ~130 (65) M bases
 constexpr int64_t PH_LARGE_MAX_TABLE_BYTES = 4ll << 30; // perfect-hash table with its first level in global memory
 
+// ---- PRESENCE FILTER of the scan kernel (nb_anchor.hip): "can any k-mer that CONTAINS this m-mer be in the library?" ---------------------
+// The scan kernel must show every seed-scan position of both orientations of a read absent from the table (88 positions of a 150-bp
+// read at k = 20); an exact test per position costs the reverse complement, the canonical choice, the two-level hash and a load, and ran
+// at the rate at which the L2s accept requests. Two facts make most of that unnecessary:
+//  * a k-mer of the table contains only m-mers of the library (m = pf_m <= k), so ONE absent m-mer rules out every k-mer that contains
+//    it: the m-mer at base q clears the k-mer positions [q - (k - m), q]. With m = k + 1 - S, S a power of two, the tests sit on a grid
+//    of S bases (S = 8 for k = 20: m = 13, seventeen tests for the 131 positions of a 150-bp read);
+//  * the filter holds ORIENTED m-mers — those of every k-mer of the table as it is and reverse-complemented — so a query needs neither
+//    the reverse complement nor the canonical form.
+// Two stages: a one-bit-per-slot table of 2^20 bits that the scan kernel copies into LDS (lf_index: a fold of the m-mer's bits, no
+// multiply; built only while it stays at most half full), and a blocked Bloom filter in global memory (two bits per m-mer inside one
+// 32-bit word: < 2 % of absent m-mers pass at the sizes pf_words_log2 picks) that is asked only for what the LDS stage lets through.
+// Only the k-mers of tiles that pass both take the exact lookup. No false negatives by construction, so results cannot change.
+NB_HD inline uint32_t pf_hash(uint64_t x) {
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  return (lo ^ ((hi << 15) | (hi >> 17))) * 0x9E3779B1u;
+}
+NB_HD inline uint32_t pf_word(uint32_t h, uint32_t wbits) { return h >> (32u - wbits); }
+NB_HD inline uint32_t pf_mask(uint32_t h) { const uint32_t g = h ^ (h >> 15); return (1u << (g & 31u)) | (1u << ((g >> 5) & 31u)); }
+constexpr uint32_t LF_BITS_LOG2 = 20;
+NB_HD inline uint32_t lf_index(uint64_t x) { return ((uint32_t)x ^ (uint32_t)(x >> 20) ^ (uint32_t)(x >> 40)) & ((1u << LF_BITS_LOG2) - 1u); }
+constexpr double LF_MAX_FILL = 0.5;                   // beyond that the LDS stage passes too much to be worth it (no lfilter is built)
+inline uint32_t pf_words_log2(int64_t n_canonical) {      // ~20+ bits per oriented m-mer, 4 KB .. 16 MB
+  uint32_t b = 10; while (b < 22 && ((int64_t)32 << b) < 40 * n_canonical) ++b; return b;
+}
+inline int pf_stride(int k) {                         // S: the largest power of two <= 16 that leaves m = k + 1 - S >= 12 (shorter m-mers turn up by chance)
+  int s = 16; while (s > 1 && k + 1 - s < 12) s >>= 1; return s;
+}
+
 // A colour (equivalence class of the graph) for the wave-per-read kernels: the span of u64 words of its bitset that can be non-zero, with
 // the first two words inline (32 bytes, two dwordx4 issued together). Bit positions are INTERNAL sequence numbers: the index builder
 // renumbers the sequences so that every connected component of the "share a k-mer" relation (a locus, for a gene-family library) starts
@@ -232,6 +261,10 @@ struct HostIndex {
   std::vector<uint32_t> akeys;        // the key words of atable alone (4 bytes per slot): what a presence / strand test needs (probes, the
                                       // other-orientation check, the scan kernel) from an array a quarter the size of the table
   std::vector<uint64_t> sparse;       // ANCHOR_LEVELS * text_len words
+  std::vector<uint32_t> pfilter;      // presence filter over the oriented k-mers of the table (above): 2^pf_wbits words
+  uint32_t pf_wbits = 0;
+  int pf_m = 0, pf_s = 1;             // m-mer length of the filters, stride S = k + 1 - m of the tests
+  std::vector<uint32_t> lfilter;      // first, LDS-sized stage of it (2^LF_BITS_LOG2 bits), empty when it would be more than half full
   int max_desc_nw = 1;                // widest class span in words (1 = every class inside one word: the lane-per-read kernels apply)
   std::vector<int32_t> perm;          // original sequence index -> internal bit position
   std::vector<int32_t> inv_perm;      // internal bit position -> original sequence index, -1 = padding

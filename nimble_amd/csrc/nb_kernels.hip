@@ -1163,7 +1163,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
   (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_scan_counts); (void)hipFree(c->d_retry_list); (void)hipFree(c->d_retry_counts); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) { if (c->h_stage_pinned) (void)hipHostFree(c->h_stage); else std::free(c->h_stage); } if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-  (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_akeys); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
+  (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
 
@@ -1187,8 +1187,8 @@ int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
   s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = h.compact ? (int64_t)h.ctable.size() * 2 : (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
   s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
   s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0; s->words_internal = h.words_dev; s->ph_table_bytes = (int64_t)(h.ph_table.size() * sizeof(PHEntry)); s->ph_pilot_bytes = (int64_t)h.ph_pilots.size();
-  s->anchor_bytes = (int64_t)(h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8);
-  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
+  s->anchor_bytes = (int64_t)(h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8);
+  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
   return NB_OK;
 }
 
@@ -1218,6 +1218,14 @@ int32_t nb_index_query(const nb_index* ix, const char* kmer, uint8_t* lext, uint
         ok = (e.pay & 0x3FFu) == (pay & 0x3FFu) && (cd.nw == 1 ? (!(e.pay & (1u << 10)) && (e.pay >> 11) == cd.w0 && e.m == cd.m0) : ((e.pay & (1u << 10)) && (e.pay >> 11) == (pay >> 10)));
       }
       if (!ok) { set_error("nb_index_query: the perfect-hash table disagrees with the compact table"); return NB_ERR_INVALID; }
+      if (found && !h.pfilter.empty()) {             // the presence filter of the scan kernel must let every m-mer of a table k-mer pass, in both orientations
+        const uint64_t mmask = (1ull << (2 * h.pf_m)) - 1, both[2] = {x, y};
+        for (int t = 0; t < 2; ++t) for (int sh = 0; sh < h.pf_s; ++sh) {
+            const uint64_t mm = (both[t] >> (2 * sh)) & mmask;
+            const uint32_t h0 = pf_hash(mm), m0 = pf_mask(h0), li = lf_index(mm);
+            if ((h.pfilter[pf_word(h0, h.pf_wbits)] & m0) != m0 || (!h.lfilter.empty() && !((h.lfilter[li >> 5] >> (li & 31u)) & 1u))) { set_error("nb_index_query: the presence filter rejects an m-mer of a k-mer of the table"); return NB_ERR_INVALID; }
+          }
+      }
     }
     if (pay == PAY_ABSENT) return 0;
     if (rext) *rext = pay & 15; if (lext) *lext = (pay >> 4) & 15; if (r_int) *r_int = (pay >> 8) & 1; if (l_int) *l_int = (pay >> 9) & 1;
@@ -1283,19 +1291,22 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
     NB_HIP(hipMemcpy(c->d_ph_table, h.ph_table.data(), h.ph_table.size() * sizeof(PHEntry), hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(c->d_ph_pilots, h.ph_pilots.data(), h.ph_pilots.size(), hipMemcpyHostToDevice));
   }
-  (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr;
-  c->has_anchor = h.has_anchor; c->text_len = h.text_len; c->anchor_nw = h.anchor_nw;
+  (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr; c->d_pfilter = nullptr; c->d_lfilter = nullptr;
+  c->has_anchor = h.has_anchor; c->pf_wbits = h.pf_wbits; c->pf_m = h.pf_m; c->pf_s = h.pf_s; c->text_len = h.text_len; c->anchor_nw = h.anchor_nw;
   if (h.has_anchor) {
     // (the sparse table is the one large piece — 8 or 16 bytes x 8 levels per library base: if it does not fit next to the caller's
     //  buffers the index still works, through the kernels that do not need it)
     const bool got = hipMalloc((void**)&c->d_atable, h.atable.size() * sizeof(AEntry)) == hipSuccess && hipMalloc((void**)&c->d_text, h.text.size() * 4) == hipSuccess &&
-                     hipMalloc((void**)&c->d_akeys, h.akeys.size() * 4) == hipSuccess && hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8) == hipSuccess;
+                     hipMalloc((void**)&c->d_akeys, h.akeys.size() * 4) == hipSuccess && hipMalloc((void**)&c->d_pfilter, h.pfilter.size() * 4) == hipSuccess &&
+                     hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8) == hipSuccess;
     if (!got) {
       (void)hipGetLastError();
-      (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr;
+      (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr; c->d_pfilter = nullptr; c->d_lfilter = nullptr;
       c->has_anchor = false;
     } else {
       NB_HIP(hipMemcpy(c->d_akeys, h.akeys.data(), h.akeys.size() * 4, hipMemcpyHostToDevice));
+      NB_HIP(hipMemcpy(c->d_pfilter, h.pfilter.data(), h.pfilter.size() * 4, hipMemcpyHostToDevice));
+      if (!h.lfilter.empty()) { NB_HIP(hipMalloc((void**)&c->d_lfilter, h.lfilter.size() * 4)); NB_HIP(hipMemcpy(c->d_lfilter, h.lfilter.data(), h.lfilter.size() * 4, hipMemcpyHostToDevice)); }
       NB_HIP(hipMemcpy(c->d_atable, h.atable.data(), h.atable.size() * sizeof(AEntry), hipMemcpyHostToDevice));
       NB_HIP(hipMemcpy(c->d_text, h.text.data(), h.text.size() * 4, hipMemcpyHostToDevice));
       NB_HIP(hipMemcpy(c->d_sparse, h.sparse.data(), h.sparse.size() * 8, hipMemcpyHostToDevice));
@@ -1315,8 +1326,31 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   if (!c->d_ct) NB_HIP(hipMalloc((void**)&c->d_ct, sizeof(DevClasses)));
   NB_HIP(hipMemcpy(c->d_ct, &c->ct, sizeof(DevClasses), hipMemcpyHostToDevice));
   c->hash = h.hash; c->W = h.words_dev; c->W_ext = h.words; c->inv_perm = h.inv_perm; c->K = h.k; c->n_seqs = h.n_seqs;
-  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); h.uploaded = 1;
+  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
+}
+
+int32_t nb_index_filter_maybe(const nb_index* ix, const char* seq, int32_t len, int32_t* m_out, int32_t* lds_stage_out) {
+  if (!ix || !seq) { set_error("nb_index_filter_maybe: null argument"); return NB_ERR_INVALID; }
+  const HostIndex& h = *ix->h;
+  if (m_out) *m_out = h.pf_m;
+  if (lds_stage_out) *lds_stage_out = h.lfilter.empty() ? 0 : 1;
+  if (h.pfilter.empty()) return 2;
+  if (len == 0) return 1;                            // (parameters only)
+  if (len < h.pf_m) { set_error("nb_index_filter_maybe: sequence shorter than the filter's m"); return NB_ERR_INVALID; }
+  const uint64_t mmask = (1ull << (2 * h.pf_m)) - 1;
+  for (int s0 = 0; s0 + h.pf_m <= len; ++s0) {
+    uint64_t x = 0;
+    for (int j = 0; j < h.pf_m; ++j) {
+      int c; switch (seq[s0 + j]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: return 1; }
+      x |= (uint64_t)c << (2 * j);
+    }
+    x &= mmask;
+    const uint32_t hh = pf_hash(x), m = pf_mask(hh), li = lf_index(x);
+    if ((h.pfilter[pf_word(hh, h.pf_wbits)] & m) != m) return 0;
+    if (!h.lfilter.empty() && !((h.lfilter[li >> 5] >> (li & 31u)) & 1u)) return 0;
+  }
+  return 1;
 }
 
 int64_t nb_packed_stride_words(int32_t max_len) { return (int64_t)((max_len + 31) / 32 + (max_len + 63) / 64); }

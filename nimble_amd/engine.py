@@ -90,6 +90,19 @@ class Index:
             return None
         return {"lext": le.value, "rext": re.value, "r_internal": ri.value, "l_internal": li.value, "members": bits_to_members(bits)}
 
+    def filter_maybe(self, seq):
+        """Presence filter of the scan kernel for a sequence as given (at least m bases): True = every m-mer of it passes (a k-mer holding
+        them may be in the library), False = some m-mer is in no k-mer of the library on either strand, None = no filter in this index."""
+        b = seq.encode() if isinstance(seq, str) else seq
+        rc = check(_lib.lib().nb_index_filter_maybe(self._h, b, len(b), None, None))
+        return None if rc == 2 else bool(rc)
+
+    def filter_params(self):
+        """(m, lds_stage_built) of the presence filter, or None."""
+        m, l = ct.c_int32(), ct.c_int32()
+        rc = check(_lib.lib().nb_index_filter_maybe(self._h, b"", 0, ct.byref(m), ct.byref(l)))
+        return None if rc == 2 else (m.value, bool(l.value))
+
     def anchor_query(self, kmer, run=0):
         """Anchor structures (csrc/nb_internal.h, AEntry) of a stranded k-mer on the host copy: None or dict(tpos, room, members = the AND
         of the classes of the text k-mers at [tpos, tpos + min(run, room)])."""

@@ -15,6 +15,7 @@ dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,18 @@ using namespace nb;
 template <class T> static T rd(FILE* f) { T v; if (std::fread(&v, sizeof v, 1, f) != 1) { std::fprintf(stderr, "short input\n"); std::exit(2); } return v; }
 
 static unsigned long long g_retried = 0;
+static int g_pf_s = 1;
+template <int NR>
+static void run_scan(const AnchorHead& h, const LaneTail* tail) {
+  switch (g_pf_s) {
+    case 16: nb_anchor_scan_kernel<NR, 16, false>(h, tail); break;
+    case 8: nb_anchor_scan_kernel<NR, 8, false>(h, tail); break;
+    case 4: nb_anchor_scan_kernel<NR, 4, false>(h, tail); break;
+    case 2: nb_anchor_scan_kernel<NR, 2, false>(h, tail); break;
+    default: nb_anchor_scan_kernel<NR, 1, false>(h, tail); break;
+  }
+}
+
 template <int NR, int NW>
 static void run_kernels(const AnchorHead& h_in, const LaneTail* tail, long long blocks, std::vector<uint32_t>* retry) {
   // one wave per workgroup, one lane per wave: block b maps read 64 * b, then (last pass) scans its own segment of the scan list.
@@ -51,7 +64,11 @@ static void run_kernels(const AnchorHead& h_in, const LaneTail* tail, long long 
         if (!retry) continue;
         h.retry_out = nullptr; h.retry_in = retry->data(); h.retry_counts = counts.data();
         nb_anchor_kernel<NR, NW, false, false>(h, tail);
-      } else { h.retry_in = nullptr; h.retry_out = nullptr; nb_anchor_scan_kernel<NR, false, false>(h, tail); }
+      } else {
+        // (the workgroup's copy of the LDS filter stage is a loop over all 1024 threads: with one lane per wave it is made here)
+        if (h.lfilter) std::memcpy(s_dyn, h.lfilter, (size_t)SCAN_LF_WORDS * 4);
+        h.retry_in = nullptr; h.retry_out = nullptr; run_scan<NR>(h, tail);
+      }
     }
 }
 
@@ -80,6 +97,7 @@ int main(int argc, char** argv) {
   if (build_host_index(n_seqs, sp.data(), sl.data(), k, &ix) != NB_OK) { std::fprintf(stderr, "index: %s\n", g_error.c_str()); return 3; }
   if (!ix->has_anchor) { std::fprintf(stderr, "index has no anchor structures\n"); return 4; }
   const int W = ix->words_dev;
+  g_pf_s = ix->pf_s;
 
   // class table on the host (same layout as nb_ctx_create makes on the device)
   const unsigned cap_log2 = 18; const size_t cap = (size_t)1 << cap_log2; const unsigned max_classes = 1u << 16;
@@ -97,7 +115,7 @@ int main(int argc, char** argv) {
   LaneTail tail{ct, a, ll, W};
   std::vector<uint32_t> scan_counts((size_t)n_reads, 0);
   AnchorHead h{ix->atable.data(), ix->akeys.data(), ix->ph_pilots.data(), ix->ph, k, ix->text.data(), ix->sparse.data(), (long long)ix->text_len, reads.data(), lens.data(), max_len, stride, nwb,
-               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0};
+               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0, ix->pfilter.data(), ix->pf_wbits, ix->lfilter.empty() ? nullptr : ix->lfilter.data()};
   std::vector<uint32_t> retry_list((size_t)n_reads * 64 + 64, 0);
   std::vector<uint32_t>* retry = std::getenv("NB_EMUL_RETRY") ? &retry_list : nullptr;
   const int positions = max_len - k + 1, nr = positions < 1 ? 1 : (positions + 63) / 64;

@@ -199,3 +199,36 @@ def test_anchor_structures(built, with_rc, alleles, wide_table, merged, monkeypa
     rng = np.random.default_rng(3)
     for _ in range(2000):
         assert ix.anchor_query("".join("ACGT"[c] for c in rng.integers(0, 4, K))) is None
+
+
+@pytest.mark.parametrize("k,n_loci,alleles,m", [(20, 20, 50, 13), (12, 2, 30, 12), (23, 6, 25, 16), (16, 4, 10, 13), (31, 3, 8, 16)])
+def test_presence_filter_has_no_false_negatives_and_few_false_positives(built, k, n_loci, alleles, m):
+    """The presence filter of the scan kernel (nb_internal.h: the m-mers, m = k + 1 - S, of every k-mer of the table in both orientations;
+    an LDS-sized one-bit table in front of a blocked Bloom filter): every stretch of a library sequence passes, as given and reverse-
+    complemented — a false negative would turn a hit into NO_HIT on the GPU; nb_index_query checks the same for each k-mer it finds — and
+    uniform random m-mers pass rarely (the kernel's exact lookups stay few)."""
+    _, _, strs, _ = library_strings(n_loci, alleles, locus_len=700, seed=77)
+    ix = engine.Index(strs, k)
+    if ix.filter_params() is None:
+        pytest.skip("library without anchor structures")
+    assert ix.filter_params()[0] == m
+    comp = str.maketrans("ACGT", "TGCA")
+    n = 0
+    for s in strs[::3]:
+        for i in range(0, len(s) - k + 1, 5):
+            km = s[i:i + k]
+            assert ix.filter_maybe(km) is True and ix.filter_maybe(km.translate(comp)[::-1]) is True, km
+            assert ix.query(km) is not None
+            n += 1
+        assert ix.filter_maybe(s) is True                                    # every m-mer of a whole sequence
+    assert n > 1000
+    rng = np.random.default_rng(9)
+    rand = ["".join("ACGT"[c] for c in rng.integers(0, 4, m)) for _ in range(20000)]
+    lib = set()
+    for s in strs:
+        for t in (s, s.translate(comp)[::-1]):
+            lib.update(t[i:i + m] for i in range(len(t) - m + 1))
+    absent = [x for x in rand if x not in lib]
+    fp = sum(ix.filter_maybe(x) for x in absent) / len(absent)
+    assert len(absent) > 10000 and fp < 0.03, (len(absent), fp)
+    assert ix.filter_maybe("ACGTN" * 8) is True                              # an N: nothing is known, the exact path decides
