@@ -53,15 +53,25 @@ struct AnchorHead {
   uint32_t* scan_counts; long long scan_seg;         // scan list: workgroup b owns entries [b * scan_seg, ...) of ll.rc_list and counts them in
                                                      // scan_counts[b] (one LDS atomic per wave instead of one contended device atomic)
   // Stragglers. A wave-batch lasts as long as its slowest lane (c2: 18 rounds for reads that need 7 on average). First pass (retry_out set):
-  // once no more than retry_lanes lanes are still walking, those reads are put on the workgroup's segment of the retry list (same segments as
-  // the scan list) and the wave moves on. Second pass (retry_in set, same grid): workgroup b maps its own segment, reads from scratch, in waves
+  // once no more than retry_lanes lanes are still walking, those reads are put on the workgroup's segment of the retry list, WITH the state of
+  // their walk (mode, position, coverage, class words, the run being followed, cover mask: 64 B), and the wave moves on. Second pass (retry_in
+  // set, same grid): workgroup b maps its own segment: the record is staged again, the walk resumes where it stopped, in waves
   // that hold nothing but long walks.
   uint32_t* retry_out; const uint32_t* retry_in; uint32_t* retry_counts; int retry_lanes, retry_rounds;
+  uint32_t* retry_state; long long retry_seg;        // the walk of a straggler as it stood at the hand-over (RetryShape<NR, NW>::DW dwords per list entry); entries per workgroup segment
   const uint32_t* pfilter; uint32_t pf_wbits;        // presence filter over the oriented k-mers of the table (nb_internal.h): 2^pf_wbits words
   const uint32_t* lfilter;                           // its LDS-sized first stage (2^20 bits), or null (library too large for it to discriminate)
 };
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+// the walk of a straggler at the hand-over to the second pass: d0 = coverage | flags << 16 | mode << 24 | rc << 26; d1 = lo | pending w0 << 16;
+// class words; pending run's text position; pending n | first-seed position << 8 | its left room << 24; first-seed anchor text position;
+// pos | run_q << 16; run_t; run_w0 | steps << 16 | maxsteps << 24; cover mask
+// cover: which seed-scan positions of the OTHER orientation (stream positions p = res + 3 j, res = last % 3) are settled — looked up, or
+// inside a verified run. One bit per lattice point: 64 NR positions hold at most 22 NR of them (one word up to NR = 3).
+template <int NR> struct CoverShape { static constexpr int LW = NR <= 3 ? 1 : 2; };
+__device__ __forceinline__ uint32_t div3(uint32_t x) { return (x * 0xAAABu) >> 17; }          // floor(x / 3), x < 98 304
+template <int NR, int NW> struct RetryShape { static constexpr int DW = (8 + 2 * NW + 2 * CoverShape<NR>::LW + 3) & ~3; };
 
 #ifdef NB_ANCHOR_PROF   // phase clock for tuning (-DNB_ANCHOR_PROF through NB_EXTRA_HIPCC_FLAGS): cycles per phase summed over waves, see scripts/anchor_phases.py
 __device__ unsigned long long g_anchor_prof[16];
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
   // the packed record of the NEXT batch is loaded into registers while this one is mapped (the reads stream from HBM exactly once)
   constexpr int MAXW = 3 * NR + 2;               // words of a record whose k-mer positions fit NR mask words (max_len <= 64 NR + 30)
   uint64_t nxt[MAXW];
-  const uint32_t* __restrict__ seg = listed ? h.retry_in + (size_t)blockIdx.x * (size_t)h.scan_seg : nullptr;
+  const uint32_t* __restrict__ seg = listed ? h.retry_in + (size_t)blockIdx.x * (size_t)h.retry_seg : nullptr;
   const long long cnt = listed ? (long long)h.retry_counts[blockIdx.x] : h.n;                       // reads of this pass / of this workgroup's segment
   const long long first = listed ? (long long)wave * 64 : ((long long)blockIdx.x * wpb + wave) * 64;
   const long long hop = listed ? (long long)wpb * 64 : nwaves * 64;
@@ -239,7 +249,15 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
 
     // ---- orientation: which strand do the k-mers at the start, the middle and the end of the read hit? A read none of whose three
     // probes is in the table at all is most likely foreign to the library: the scan kernel settles it (no walk, no divergence here) ----
-    if (last >= 0) {
+    constexpr int RDW = RetryShape<NR, NW>::DW;
+    uint32_t rs[RDW];                              // (second pass: the saved walk of this lane's read)
+    if (listed) {
+      const uint32_t* sp = h.retry_state + ((size_t)blockIdx.x * (size_t)h.retry_seg + (size_t)(idx < cnt ? idx : 0)) * RDW;
+#pragma unroll
+      for (int q4 = 0; q4 < RDW / 4; ++q4) { const uint4 v = *reinterpret_cast<const uint4*>(sp + 4 * q4); rs[4 * q4] = v.x; rs[4 * q4 + 1] = v.y; rs[4 * q4 + 2] = v.z; rs[4 * q4 + 3] = v.w; }
+      rcf = active && ((rs[0] >> 26) & 1u);
+      if (rcf) R.stream_rc();
+    } else if (last >= 0) {
       int votes = 0; bool any = false;
       LookKey pk[3]; bool pv[3];
 #pragma unroll
@@ -292,21 +310,65 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         v1 = (((uint64_t)x.w << 32) | x.z) & (((uint64_t)y.w << 32) | y.z);
       }
     };
-    Mask<NR> cover;                             // positions whose status on BOTH strands is known: looked up, or inside a verified run
+    constexpr int LW = CoverShape<NR>::LW;
+    uint64_t cover[LW];                         // settled seed-scan positions of the other orientation (CoverShape)
 #pragma unroll
-    for (int wi = 0; wi < NR; ++wi) cover.w[wi] = 0;
+    for (int wi = 0; wi < LW; ++wi) cover[wi] = 0;
+    const int res = last >= 0 ? last % 3 : 0;
+    auto cover_set = [&](int j0, int j1) {      // lattice points j0 .. j1 (nothing if j1 < j0)
+#pragma unroll
+      for (int wi = 0; wi < LW; ++wi) {
+        const int a = j0 - 64 * wi, b = j1 - 64 * wi;
+        const uint64_t hi = b >= 63 ? ~0ull : (b < 0 ? 0ull : ((2ull << b) - 1)), lo_ = a <= 0 ? ~0ull : (a >= 64 ? 0ull : (~0ull << a));
+        cover[wi] |= (j1 >= j0) ? (hi & lo_) : 0ull;
+      }
+    };
     const int L5 = L / 5;
     int ls_q = 0, ls_room = 0; uint32_t ls_t = 0;   // first seed with a possible left extension: its position, anchor and left room
     int rounds = 0;
 #ifdef NB_ANCHOR_PROF
     int my_rounds = 0;
 #endif
-    bool to_retry = false;
+    if (listed && active) {                        // the walk resumes where the first pass left it
+      constexpr int B = 2 + 2 * NW;
+      cov = (int)(rs[0] & 0xFFFFu); fl = (rs[0] >> 16) & 0xFFu; mode = (int)((rs[0] >> 24) & 3u);
+      lo = rs[1] & 0xFFFFu; p_w0 = rs[1] >> 16;
+      a0 = ((uint64_t)rs[3] << 32) | rs[2]; if (NW > 1) a1 = ((uint64_t)rs[B - 1] << 32) | rs[B - 2];
+      p_t = rs[B]; p_n = rs[B + 1] & 0xFFu; ls_q = (int)((rs[B + 1] >> 8) & 0xFFFFu); ls_room = (int)(rs[B + 1] >> 24); ls_t = rs[B + 2];
+      pos = (int)(rs[B + 3] & 0xFFFFu); run_q = (int)(rs[B + 3] >> 16); run_t = rs[B + 4];
+      run_w0 = rs[B + 5] & 0xFFFFu; steps = (int)((rs[B + 5] >> 16) & 0xFFu); maxsteps = (int)(rs[B + 5] >> 24);
+#pragma unroll
+      for (int wi = 0; wi < LW; ++wi) cover[wi] = ((uint64_t)rs[B + 7 + 2 * wi] << 32) | rs[B + 6 + 2 * wi];
+    }
     uint64_t busy;
     while ((busy = __ballot(mode != DONE)) != 0) {
       if (h.retry_out && rounds >= h.retry_rounds && __popcll(busy) <= h.retry_lanes) {   // the few lanes left hold the whole wave: second pass
-        to_retry = mode != DONE;
-        if (to_retry) { mode = DONE; p_n = 0u; fl = 0u; active = false; }     // (nothing below touches this read: no outputs, no lists but the retry list)
+        // the read and its walk as it stands go on the workgroup's segment of the retry list (one LDS atomic per wave)
+        const bool to_retry = mode != DONE;
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&s_retry_n, (uint32_t)__popcll(busy));
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        if (to_retry) {
+          const size_t slot = (size_t)blockIdx.x * (size_t)h.retry_seg + b0 + (uint32_t)__popcll(busy & ((1ull << lane) - 1));
+          h.retry_out[slot] = r;
+          constexpr int B = 2 + 2 * NW;
+          uint32_t d[RDW];
+#pragma unroll
+          for (int j = 0; j < RDW; ++j) d[j] = 0u;
+          d[0] = (uint32_t)(cov & 0xFFFF) | ((fl & 0xFFu) << 16) | ((uint32_t)mode << 24) | ((rcf ? 1u : 0u) << 26);
+          d[1] = (lo & 0xFFFFu) | (p_w0 << 16);
+          d[2] = (uint32_t)a0; d[3] = (uint32_t)(a0 >> 32);
+          if (NW > 1) { d[B - 2] = (uint32_t)a1; d[B - 1] = (uint32_t)(a1 >> 32); }
+          d[B] = p_t; d[B + 1] = (p_n & 0xFFu) | (((uint32_t)ls_q & 0xFFFFu) << 8) | (((uint32_t)ls_room & 0xFFu) << 24); d[B + 2] = ls_t;
+          d[B + 3] = ((uint32_t)pos & 0xFFFFu) | ((uint32_t)run_q << 16); d[B + 4] = run_t;
+          d[B + 5] = (run_w0 & 0xFFFFu) | (((uint32_t)steps & 0xFFu) << 16) | (((uint32_t)maxsteps & 0xFFu) << 24);
+#pragma unroll
+          for (int wi = 0; wi < LW; ++wi) { d[B + 6 + 2 * wi] = (uint32_t)cover[wi]; d[B + 7 + 2 * wi] = (uint32_t)(cover[wi] >> 32); }
+          uint32_t* sp = h.retry_state + slot * RDW;
+#pragma unroll
+          for (int q4 = 0; q4 < RDW / 4; ++q4) { uint4 v; v.x = d[4 * q4]; v.y = d[4 * q4 + 1]; v.z = d[4 * q4 + 2]; v.w = d[4 * q4 + 3]; *reinterpret_cast<uint4*>(sp + 4 * q4) = v; }
+          mode = DONE; p_n = 0u; fl = 0u; active = false;                      // (nothing below touches this read: no outputs, no lists)
+        }
         break;
       }
 #ifdef NB_ANCHOR_PROF
@@ -341,8 +403,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
           maxsteps = room < rem ? room : rem;
           mode = EXT;
         } else if (act) {
-#pragma unroll
-          for (int wi = 0; wi < NR; ++wi) cover.w[wi] |= ((q >> 6) == wi) ? (1ull << (q & 63)) : 0ull;
+          { const uint32_t j = div3((uint32_t)(q + 3 - res)); if ((int)(3u * j) == q + 3 - res) cover_set((int)j - 1, (int)j - 1); }     // (a looked-up position on the lattice)
           if (step) mode = pos > last ? DONE : SEEK;                          // the walk broke at base pos: seed scan from there (SPEC §3)
           else { pos += 3; mode = pos > last ? DONE : SEEK; }
         }
@@ -373,7 +434,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         if (fin) {                                                            // the run [run_q, run_q + steps] is complete
           cov += ((fl & F_STEP) ? 1 : K) + steps;
           p_t = run_t; p_n = (uint32_t)steps + 1u; p_w0 = run_w0;
-          set_range<NR>(cover, run_q, run_q + steps);
+          cover_set((int)div3((uint32_t)(run_q - res + 2 + 3)) - 1, (int)div3((uint32_t)(run_q + steps - res + 3)) - 1);   // lattice points inside [run_q, run_q + steps]
           pos = run_q + K + steps;                                            // the base the run stopped at
           mode = pos >= L ? DONE : STEP;
         }
@@ -437,30 +498,33 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
 
     // ---- the other orientation: does any of ITS seed-scan positions hit? (stream positions p = last, last - 3, ... not yet known) ----
     {
-      Mask<NR> todo;
-      const uint64_t PAT = 0x9249249249249249ull;
+      uint64_t todo[LW];                                                        // lattice points (p = res + 3 j, j <= last / 3) not settled yet
       const bool need = active && last >= 0 && !to_scan && !(fl & F_REDO);
+      const int jmax = last >= 0 ? (int)div3((uint32_t)last) : -1;
 #pragma unroll
-      for (int wi = 0; wi < NR; ++wi) {
-        const int res = ((last % 3 + 3) % 3 - (wi % 3) + 3) % 3;           // (last < 0 for reads shorter than k: keep the shift count in range)
-        uint64_t m = (PAT << res) & ~cover.w[wi];
-        const int top = last - wi * 64;                                       // positions <= last only
-        m &= top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
-        todo.w[wi] = need ? m : 0ull;
+      for (int wi = 0; wi < LW; ++wi) {
+        const int top = jmax - 64 * wi;
+        const uint64_t m = top >= 63 ? ~0ull : (top < 0 ? 0ull : ((2ull << top) - 1));
+        todo[wi] = need ? (m & ~cover[wi]) : 0ull;
       }
+      auto any_todo = [&]() { uint64_t v = 0;
+#pragma unroll
+        for (int wi = 0; wi < LW; ++wi) v |= todo[wi];
+        return v != 0; };
       // (tried: the presence filter of the scan kernel in front of these lookups. c2 3.52 ms against 3.21: the positions are few and per
       //  lane, so the filter saves no request — one 4-byte load either way — and the second loop for the positions that pass costs more
       //  than the shorter hash saves; profiles/r03_tuning_notes.md)
-      while (__ballot(any_set<NR>(todo))) {
+      while (__ballot(any_todo())) {
         constexpr int U = 8;
         LookKey kk[U]; bool vv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          int p = -1;
+          int j = -1;
 #pragma unroll
-          for (int wi = 0; wi < NR; ++wi) if (p < 0 && todo.w[wi]) { p = wi * 64 + __builtin_ctzll(todo.w[wi]); todo.w[wi] &= todo.w[wi] - 1; }
-          uint64_t w; uint32_t nn; R.get32(p < 0 ? 0 : p, w, nn);
-          vv[u] = p >= 0 && (nn & nkmask) == 0;
+          for (int wi = 0; wi < LW; ++wi) if (j < 0 && todo[wi]) { j = wi * 64 + __builtin_ctzll(todo[wi]); todo[wi] &= todo[wi] - 1; }
+          const int p = j < 0 ? 0 : res + 3 * j;
+          uint64_t w; uint32_t nn; R.get32(p, w, nn);
+          vv[u] = j >= 0 && (nn & nkmask) == 0;
           kk[u] = anchor_lookup_key<PLDS>(h, s_pilots, w & kmask, vv[u]);
         }
 #pragma unroll
@@ -472,21 +536,12 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         }
         if (fl & F_OPP) {
 #pragma unroll
-          for (int wi = 0; wi < NR; ++wi) todo.w[wi] = 0;
+          for (int wi = 0; wi < LW; ++wi) todo[wi] = 0;
         }
       }
     }
 
     PROF_MARK(3);
-    {
-      const uint64_t mr_ = __ballot(to_retry);
-      if (mr_) {
-        uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&s_retry_n, (uint32_t)__popcll(mr_));
-        b0 = __builtin_amdgcn_readfirstlane(b0);
-        if (to_retry) h.retry_out[(size_t)blockIdx.x * (size_t)h.scan_seg + b0 + (uint32_t)__popcll(mr_ & ((1ull << lane) - 1))] = r;
-      }
-    }
     if (MATE) {                                                               // paired path: the raw alignment of this mate, no decision here
       if (active) {
         uint32_t st = MATE_OK;
@@ -923,7 +978,8 @@ static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_
   AnchorHead h = h_in;                                               // scan-list segment of a workgroup: as many entries as it has reads
   h.scan_seg = ((h.n + blocks * waves * 64 - 1) / (blocks * waves * 64)) * waves * 64;
   if (blocks * h.scan_seg > c->scan_list_cap || blocks > c->scan_counts_cap) { set_error("launch_anchor: scan list too small"); return NB_ERR_INVALID; }
-  int retry_lanes = 6;                                               // (c2: 8.7 % of the reads walk for more than 12 rounds, waves for 18)
+  int retry_lanes = 12;                                              // (c2: 8.7 % of the reads walk for more than 12 rounds, waves for 18; with the walk's state handed over the thresholds
+                                                                     //  hardly matter: 6 .. 28 lanes after 8 .. 12 rounds all give 2.98 .. 3.05 ms, profiles/r03c_retry_sweep.txt)
   if (const char* e = std::getenv("NB_ANCHOR_RETRY_LANES")) { const int v = std::atoi(e); if (v >= 0 && v < 64) retry_lanes = v; }
   long long retry_min = 64LL * 64 * waves;                           // (small batches: nothing to gain from a second launch)
   if (const char* e = std::getenv("NB_ANCHOR_RETRY_MIN")) retry_min = std::atoll(e);
@@ -931,11 +987,17 @@ static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_
   //  c5 58.8 -> 60.9 ms with the pass; c2 3.37 -> 3.19 ms, paired templates 1 249 -> 1 343 M pairs/s, c3 unchanged)
   c->anchor_retry_ran = PLDS && retry_lanes > 0 && h.n >= retry_min;
   if (c->anchor_retry_ran) {
-    if (c->retry_cap < c->scan_list_cap || !c->d_retry_counts) {
-      (void)hipFree(c->d_retry_list); (void)hipFree(c->d_retry_counts); c->d_retry_list = nullptr; c->d_retry_counts = nullptr; c->retry_cap = 0;
-      NB_HIP(hipMalloc((void**)&c->d_retry_list, (size_t)c->scan_list_cap * 4)); NB_HIP(hipMalloc((void**)&c->d_retry_counts, (size_t)c->scan_counts_cap * 4));
-      c->retry_cap = c->scan_list_cap;
+    // a wave-batch hands over at most retry_lanes reads: that bounds a workgroup's segment of the list (ids + RetryShape::DW dwords of state each)
+    h.retry_seg = (h.scan_seg / 64) * retry_lanes + 64;
+    const int64_t need = (int64_t)blocks * h.retry_seg;
+    constexpr int RDW = RetryShape<NR, NW>::DW;
+    if (c->retry_cap < need || c->retry_state_dw < RDW || !c->d_retry_counts) {
+      (void)hipFree(c->d_retry_list); (void)hipFree(c->d_retry_counts); (void)hipFree(c->d_retry_state); c->d_retry_list = nullptr; c->d_retry_counts = nullptr; c->d_retry_state = nullptr; c->retry_cap = 0;
+      NB_HIP(hipMalloc((void**)&c->d_retry_list, (size_t)need * 4)); NB_HIP(hipMalloc((void**)&c->d_retry_counts, (size_t)c->scan_counts_cap * 4));
+      NB_HIP(hipMalloc((void**)&c->d_retry_state, (size_t)need * RDW * 4));
+      c->retry_cap = need; c->retry_state_dw = RDW;
     }
+    h.retry_state = c->d_retry_state;
     h.retry_out = c->d_retry_list; h.retry_in = nullptr; h.retry_counts = c->d_retry_counts; h.retry_lanes = retry_lanes;
     h.retry_rounds = 10;                                             // (short reads — c3, 91 bp — finish in fewer rounds than that: nothing handed over, nothing lost)
     if (const char* e = std::getenv("NB_ANCHOR_RETRY_ROUNDS")) h.retry_rounds = std::atoi(e);
@@ -982,7 +1044,7 @@ static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads
   return AnchorHead{c->d_atable, c->d_akeys, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
                     (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out,
-                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0, c->d_pfilter, c->pf_wbits, c->d_lfilter};
+                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, c->d_pfilter, c->pf_wbits, c->d_lfilter};
 }
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {

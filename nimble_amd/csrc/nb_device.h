@@ -379,7 +379,7 @@ struct nb_ctx {
   uint64_t* d_redo_reads = nullptr; int64_t redo_words_cap = 0; uint16_t* d_redo_lens = nullptr; uint32_t* d_redo_out = nullptr;   // gathered redo reads + their results (4 u32 per read)
   void* d_lane_tail = nullptr;     // LaneTail of the current batch (nb_lane.hip)
   nb::PHEntry* d_ph_table = nullptr; uint8_t* d_ph_pilots = nullptr; nb::PHash ph{}; bool has_ph = false;   // perfect-hash table of the lane kernels
-  uint32_t* d_retry_list = nullptr; uint32_t* d_retry_counts = nullptr; int64_t retry_cap = 0;   // stragglers of the anchor kernel's first pass (nb_anchor.hip)
+  uint32_t* d_retry_list = nullptr; uint32_t* d_retry_counts = nullptr; int64_t retry_cap = 0; uint32_t* d_retry_state = nullptr; int retry_state_dw = 0;   // stragglers of the anchor kernel's first pass (nb_anchor.hip)
   bool anchor_retry_ran = false;   // the last launch_anchor / launch_anchor_pairs ran the second pass (reported in last_kernels)
   uint32_t* d_akeys = nullptr;     // key words of d_atable alone (nb_internal.h, akeys)
   uint32_t* d_lfilter = nullptr;   // first stage of the presence filter (copied to LDS by the scan kernel), null if not built

@@ -1162,7 +1162,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
-  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_scan_counts); (void)hipFree(c->d_retry_list); (void)hipFree(c->d_retry_counts); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) { if (c->h_stage_pinned) (void)hipHostFree(c->h_stage); else std::free(c->h_stage); } if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_scan_counts); (void)hipFree(c->d_retry_list); (void)hipFree(c->d_retry_counts); (void)hipFree(c->d_retry_state); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) { if (c->h_stage_pinned) (void)hipHostFree(c->h_stage); else std::free(c->h_stage); } if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
@@ -1434,8 +1434,8 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     { char buf[240];
       if (use_anchor) {
         char ak[80]; std::snprintf(ak, sizeof ak, "nb_anchor_kernel<%d, %d, %s, false>", nr > 5 ? 5 : nr, c->anchor_nw, anchor_pilots_in_lds(c, max_len) ? "true" : "false");
-        std::snprintf(buf, sizeof buf, "%s;%s%snb_anchor_scan_kernel<%d, %s, false>", ak, c->anchor_retry_ran ? ak : "", c->anchor_retry_ran ? ";" : "",   // (second launch: the stragglers' retry list)
-                      nr > 5 ? 5 : nr, anchor_pilots_in_lds(c, max_len) ? "true" : "false");
+        std::snprintf(buf, sizeof buf, "%s;%s%snb_anchor_scan_kernel<%d, %d, false>", ak, c->anchor_retry_ran ? ak : "", c->anchor_retry_ran ? ";" : "",   // (second launch: the stragglers' retry list)
+                      nr > 5 ? 5 : nr, c->pf_s);
       }
       else std::snprintf(buf, sizeof buf, "nb_lane_kernel<%d, 0>;nb_lane_kernel<%d, 1>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr);
       c->last_kernels = buf; }

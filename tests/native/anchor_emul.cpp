@@ -48,11 +48,14 @@ static void run_scan(const AnchorHead& h, const LaneTail* tail) {
 template <int NR, int NW>
 static void run_kernels(const AnchorHead& h_in, const LaneTail* tail, long long blocks, std::vector<uint32_t>* retry) {
   // one wave per workgroup, one lane per wave: block b maps read 64 * b, then (last pass) scans its own segment of the scan list.
-  // retry: every other read is handed to the second pass of nb_anchor_kernel after its first round (retry_lanes = 1 with one lane per wave,
-  // switched per block), which maps its segment of the retry list from scratch.
+  // retry: every other read is handed to the second pass of nb_anchor_kernel after NB_EMUL_RETRY rounds (retry_lanes = 1 with one lane per
+  // wave, switched per block), with the state of its walk; the second pass resumes it.
   blockDim = dim3(64); gridDim = dim3((unsigned)blocks); threadIdx = dim3(0);
   AnchorHead h = h_in;
   std::vector<uint32_t> counts((size_t)blocks, 0);
+  std::vector<uint32_t> state(retry ? ((size_t)blocks * 64 + 64) * RetryShape<NR, NW>::DW : 0, 0xDEADBEEFu);
+  h.retry_state = state.data(); h.retry_seg = 64;
+  h.retry_rounds = retry ? std::atoi(std::getenv("NB_EMUL_RETRY")) : 0;          // NB_EMUL_RETRY=<rounds>: hand over after that many rounds (0 = before the first)
   for (int pass = 0; pass < 3; ++pass)
     for (long long b = 0; b < blocks; ++b) {
       blockIdx = dim3((unsigned)b);
@@ -115,7 +118,7 @@ int main(int argc, char** argv) {
   LaneTail tail{ct, a, ll, W};
   std::vector<uint32_t> scan_counts((size_t)n_reads, 0);
   AnchorHead h{ix->atable.data(), ix->akeys.data(), ix->ph_pilots.data(), ix->ph, k, ix->text.data(), ix->sparse.data(), (long long)ix->text_len, reads.data(), lens.data(), max_len, stride, nwb,
-               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0, ix->pfilter.data(), ix->pf_wbits, ix->lfilter.empty() ? nullptr : ix->lfilter.data()};
+               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, ix->pfilter.data(), ix->pf_wbits, ix->lfilter.empty() ? nullptr : ix->lfilter.data()};
   std::vector<uint32_t> retry_list((size_t)n_reads * 64 + 64, 0);
   std::vector<uint32_t>* retry = std::getenv("NB_EMUL_RETRY") ? &retry_list : nullptr;
   const int positions = max_len - k + 1, nr = positions < 1 ? 1 : (positions + 63) / 64;

@@ -41,20 +41,21 @@ def _run(emul, tmp_path, strs, k, reads, max_len, cfg, max_redo_frac):
         f.write(np.ascontiguousarray(lens, dtype=np.uint16).tobytes())
         f.write(struct.pack("<iiiid", cfg.score_threshold, cfg.score_filter, cfg.discard_multiple_matches, cfg.strand_filter, cfg.score_percent))
     ora = oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=4)
-    # twice: one pass of nb_anchor_kernel, and with every other read handed to its second pass (the stragglers' retry list)
-    for retry in (True, False):
+    # one pass of nb_anchor_kernel, and with every other read handed to its second pass (the stragglers' retry list, with the state of the
+    # walk) before its first round, after two rounds and after five
+    for retry in (0, 2, 5, None):
         got, log = _emulate(emul, inp, out, retry)
         _compare(got, ora, max_redo_frac, log)
         retried = int(log.split("retried ")[1].split(",")[0])
-        assert (retried > 0) == (retry and len(reads) > 50), log
+        assert (retried > 0) == (retry is not None and len(reads) > 50), log
     return got, ora, log
 
 
 def _emulate(emul, inp, out, retry):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     env.pop("NB_EMUL_RETRY", None)
-    if retry:
-        env["NB_EMUL_RETRY"] = "1"
+    if retry is not None:
+        env["NB_EMUL_RETRY"] = str(retry)
     r = subprocess.run([emul, inp, out], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     raw = open(out, "rb").read()
