@@ -12,15 +12,15 @@ python bench.py --config $CFG --steps $STEPS --warmup 1 > "$OUT/bench.json" 2> "
 cut -c1-400 "$OUT/bench.json"
 Q="--config $CFG --warmup 1 --no-cpu-baseline --parity-sample 0"
 echo "== rocprofv3 kernel trace + stats =="
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps $STEPS $Q > "$OUT/trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps $STEPS $Q > "$OUT/trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
 for pass in "pmc_fetch FETCH_SIZE" "pmc_write WRITE_SIZE" "pmc_l2 TCC_HIT_sum TCC_MISS_sum"; do
   set -- $pass; name=$1; shift
   echo "== rocprofv3 PMC: $* =="
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o bench -- python3 bench.py --steps 2 $Q > "$OUT/$name.json" 2> "$OUT/$name.err" || { tail -5 "$OUT/$name.err"; exit 1; }
+  timeout -k 10 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o bench -- python3 bench.py --steps 2 $Q > "$OUT/$name.json" 2> "$OUT/$name.err" || { tail -5 "$OUT/$name.err"; exit 1; }
 done
 # optional pass (counter names differ between ROCm releases; a missing counter must not lose the passes above): L1 -> L2 requests
 echo "== rocprofv3 PMC: TCP_TCC_READ_REQ_sum (optional) =="
-rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/pmc_l1" -o bench -- python3 bench.py --steps 2 $Q > "$OUT/pmc_l1.json" 2> "$OUT/pmc_l1.err" || echo "(TCP_TCC_READ_REQ_sum not collected)"
+timeout -k 10 900 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/pmc_l1" -o bench -- python3 bench.py --steps 2 $Q > "$OUT/pmc_l1.json" 2> "$OUT/pmc_l1.err" || echo "(TCP_TCC_READ_REQ_sum not collected)"
 python scripts/summarize_profile.py "$OUT" "$CFG" > "$OUT/summary.txt"
 cat "$OUT/summary.txt"
 # keep what is merged back small (gpurun copies gpurun_out/ back only below 64 MiB)
