@@ -718,7 +718,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_scan_kernel(AnchorHead h, cons
     const int nblk = h.max_len >= K ? (h.max_len - K + S - 1) / 16 + 1 : 0;     // blocks that hold a tile's m-mer start
     // chunks of blocks (~10-16 tiles): first every LDS word of the chunk, then every filter word, then the verdicts — straight-line code
     // with unconditional loads (an index that does not matter is 0), so that a chunk costs two round trips whatever it holds
-    constexpr int CH = S >= 16 ? MAXBLK : (S == 8 ? 5 : (S == 4 ? 3 : (S == 2 ? 2 : 1))), NT = CH * TPB;
+    constexpr int CH = S == 8 ? 5 : (S == 4 ? 3 : (S == 2 ? 2 : 1)), NT = CH * TPB;
 #pragma unroll
     for (int c0 = 0; c0 < MAXBLK; c0 += CH) {
       if (c0 < nblk && __ballot(act && 16 * c0 - (S - 1) <= last)) {
@@ -958,7 +958,6 @@ static int launch_scan_t(const AnchorHead& h, const LaneTail* d_tail, long long 
 template <int NR, bool MATE>
 static int launch_scan_s(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, long long blocks, int waves, hipStream_t s) {
   switch (c->pf_s) {                                                  // stride of the presence filter's tiles (pf_stride(k), nb_internal.h)
-    case 16: return launch_scan_t<NR, 16, MATE>(h, d_tail, blocks, waves, s);
     case 8: return launch_scan_t<NR, 8, MATE>(h, d_tail, blocks, waves, s);
     case 4: return launch_scan_t<NR, 4, MATE>(h, d_tail, blocks, waves, s);
     case 2: return launch_scan_t<NR, 2, MATE>(h, d_tail, blocks, waves, s);

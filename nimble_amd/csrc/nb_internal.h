@@ -202,8 +202,8 @@ constexpr double LF_MAX_FILL = 0.5;                   // beyond that the LDS sta
 inline uint32_t pf_words_log2(int64_t n_canonical) {      // ~20+ bits per oriented m-mer, 4 KB .. 16 MB
   uint32_t b = 10; while (b < 22 && ((int64_t)32 << b) < 40 * n_canonical) ++b; return b;
 }
-inline int pf_stride(int k) {                         // S: the largest power of two <= 16 that leaves m = k + 1 - S >= 12 (shorter m-mers turn up by chance)
-  int s = 16; while (s > 1 && k + 1 - s < 12) s >>= 1; return s;
+inline int pf_stride(int k) {                         // S: the largest power of two <= 8 that leaves m = k + 1 - S >= 12 (shorter m-mers turn up by chance;
+  int s = 8; while (s > 1 && k + 1 - s < 12) s >>= 1; return s;   //  the anchor structures exist for k <= 23 only: m <= 16)
 }
 
 // A colour (equivalence class of the graph) for the wave-per-read kernels: the span of u64 words of its bitset that can be non-zero, with

@@ -22,7 +22,7 @@ def scenario(seed):
     loci, alleles = int(rng.choice([1, 3, 8, 20, 40])), int(rng.choice([2, 10, 50, 70]))
     L = int(rng.choice([40, 64, 91, 150, 151, 250, 339]))
     locus_len = int(rng.choice([max(L + 20, 300), 600, 1098]))
-    k = int(rng.choice([20, 20, 20, 16, 23, 12, 22, 27, 31, 9]))
+    k = int(rng.choice([20, 20, 20, 16, 23, 12, 22, 27, 31, 9, 13, 14, 15, 19, 26]))          # (presence-filter strides 1, 2, 4, 8 all occur)
     if rng.random() < 0.08:
         loci, alleles = int(rng.choice([60, 100])), 70                    # classes of two words, thousands of sequences
     _, seqs, strs, _ = library_strings(loci, alleles, locus_len=locus_len, seed=seed)

@@ -37,7 +37,6 @@ static int g_pf_s = 1;
 template <int NR>
 static void run_scan(const AnchorHead& h, const LaneTail* tail) {
   switch (g_pf_s) {
-    case 16: nb_anchor_scan_kernel<NR, 16, false>(h, tail); break;
     case 8: nb_anchor_scan_kernel<NR, 8, false>(h, tail); break;
     case 4: nb_anchor_scan_kernel<NR, 4, false>(h, tail); break;
     case 2: nb_anchor_scan_kernel<NR, 2, false>(h, tail); break;

@@ -261,3 +261,44 @@ def test_awkward_libraries(built, seed, k_over):
         return
     gpu = run_gpu(engine.Index(strs, k), cfg, words, lens, max_len)
     assert_same(gpu, oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=4), f"awkward library {seed} (k={k}, kernels {gpu['kernels']})")
+
+
+@pytest.mark.parametrize("k,loci,alleles,lds_stage", [(20, 8, 20, True), (12, 3, 10, True), (14, 3, 10, True), (16, 4, 10, True), (23, 4, 10, True), (20, 60, 70, False)])
+def test_scan_kernel_behind_the_presence_filter(built, k, loci, alleles, lds_stage):
+    """nb_anchor_scan_kernel settles the reads none of whose three probes hits through the presence filter (one m-mer per tile of S k-mer
+    positions: LDS stage, blocked Bloom filter, exact lookup for what passes; strides S = 1, 2, 4, 8 by k; the last library is too large
+    for the LDS stage). Foreign reads must come out NO_HIT, and a read that hides ONE library k-mer — at every offset, in either
+    orientation, next to an N, at the very end of a ragged read — must be found and handed to the wave-per-read kernel, whose result equals
+    the oracle's like everything else."""
+    rng = np.random.default_rng(1000 + k + loci)
+    _, _, strs, _ = library_strings(loci, alleles, locus_len=500, seed=300 + k)
+    ix = engine.Index(strs, k)
+    assert ix.filter_params() is not None and ix.filter_params()[1] == lds_stage, ix.filter_params()
+    L = 150
+    rnd = lambda n: "".join("ACGT"[c] for c in rng.integers(0, 4, n))        # noqa: E731
+    reads = [rnd(L) for _ in range(3000)]                                     # foreign
+    hidden = []
+    for off in range(0, L - k + 1):                                           # one library k-mer at every offset, both orientations
+        s = strs[int(rng.integers(0, len(strs)))]
+        o = int(rng.integers(0, len(s) - k + 1))
+        km = s[o:o + k]
+        for kk in (km, rc(km)):
+            r = rnd(L)
+            hidden.append(r[:off] + kk + r[off + k:])
+    reads += hidden
+    reads += [r[:70] + "N" + r[71:] for r in hidden[::7]]                     # an N somewhere (inside the k-mer for some)
+    reads += [r[:int(rng.integers(k, L + 1))] for r in hidden[::5]]           # ragged: the planted k-mer may be cut off
+    reads += [rnd(int(rng.integers(0, k))) for _ in range(20)] + ["N" * L, "A" * L, "ACGT" * 37]
+    # library reads whose probe positions (first, middle, last k-mer) are all hit by an error: they reach the scan kernel too
+    for _ in range(300):
+        s = strs[int(rng.integers(0, len(strs)))]
+        o = int(rng.integers(0, len(s) - L + 1))
+        r = list(s[o:o + L])
+        last = L - k
+        for p in (k // 2, last // 2 + k // 2, last + k // 2):
+            r[p] = "ACGT"[("ACGT".index(r[p]) + 1) % 4] if r[p] in "ACGT" else "A"
+        reads.append("".join(r))
+    cfg = engine.make_config(k=k, score_threshold=k, score_filter=k)
+    ora = _check(strs, k, reads, L, f"scan kernel, k={k}", cfg=cfg)
+    no_hit = int((ora["reason"] == 2).sum())
+    assert no_hit >= 2500 and int((ora["reason"] != 2).sum()) > 200, (no_hit, len(reads))

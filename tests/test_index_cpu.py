@@ -201,7 +201,7 @@ def test_anchor_structures(built, with_rc, alleles, wide_table, merged, monkeypa
         assert ix.anchor_query("".join("ACGT"[c] for c in rng.integers(0, 4, K))) is None
 
 
-@pytest.mark.parametrize("k,n_loci,alleles,m", [(20, 20, 50, 13), (12, 2, 30, 12), (23, 6, 25, 16), (16, 4, 10, 13), (31, 3, 8, 16)])
+@pytest.mark.parametrize("k,n_loci,alleles,m", [(20, 20, 50, 13), (12, 2, 30, 12), (23, 6, 25, 16), (16, 4, 10, 13), (31, 3, 8, 24)])
 def test_presence_filter_has_no_false_negatives_and_few_false_positives(built, k, n_loci, alleles, m):
     """The presence filter of the scan kernel (nb_internal.h: the m-mers, m = k + 1 - S, of every k-mer of the table in both orientations;
     an LDS-sized one-bit table in front of a blocked Bloom filter): every stretch of a library sequence passes, as given and reverse-
