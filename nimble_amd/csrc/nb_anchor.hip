@@ -383,11 +383,28 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         const uint64_t x = (step ? (w >> 2) : w) & kmask;
         const bool valid = act && (((step ? (nn >> 1) : nn) & nkmask) == 0);
         const bool havep = act && p_n != 0u;
-        uint64_t s0 = ~0ull, s1 = ~0ull;
-        if (havep) range_and(p_t, p_n, s0, s1);
+        // the pending run's two sparse-table operands: loaded unconditionally (entry 0 for lanes without a pending run) and combined only
+        // AFTER the table lookup has been issued — inside a conditional block the compiler waited for them before it issued the lookup,
+        // two dependent round trips per round instead of one
+        uint64_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        {
+          const uint32_t n = havep ? p_n : 1u;
+          const int lv = 31 - __builtin_clz(n);
+          uint32_t off = n - (1u << lv), t = havep ? p_t : 0u;
+          if (!CHK(n >= 1u && n < 256u && ((long long)lv * h.T + t + off + 1) * NW <= h.sparse_words, 13)) { t = 0u; off = 0u; }
+#ifdef NB_ANCHOR_PROF
+          if (h.dbg & 1) { t = 0u; off = 0u; }
+#endif
+          const uint64_t* sp = h.sparse + ((size_t)(havep && n < 256u ? lv : 0) * (size_t)h.T + t) * NW;
+          if (NW == 1) { x0 = sp[0]; y0 = sp[off]; }
+          else {
+            const uint4 xa = *reinterpret_cast<const uint4*>(sp), ya = *reinterpret_cast<const uint4*>(sp + 2 * (size_t)off);
+            x0 = ((uint64_t)xa.y << 32) | xa.x; x1 = ((uint64_t)xa.w << 32) | xa.z; y0 = ((uint64_t)ya.y << 32) | ya.x; y1 = ((uint64_t)ya.w << 32) | ya.z;
+          }
+        }
         const Look k = anchor_lookup<PLDS>(h, s_pilots, x, valid);
         const uint32_t d = k.e.x ^ k.want, pay = k.e.y;
-        if (havep) { fold(s0, s1, p_w0); p_n = 0u; }
+        if (havep) { fold(x0 & y0, x1 & y1, p_w0); p_n = 0u; }
         const bool found = valid && d < 4u, both = found && (d & 2u);
         const bool hS = found && !both && ((d & 1u) == (k.o ? 1u : 0u));
         fl |= (both ? F_HARD : 0u) | ((found && !both && !hS) ? F_OPP : 0u);
