@@ -188,7 +188,7 @@ constexpr int64_t PH_LARGE_MAX_TABLE_BYTES = 4ll << 30; // perfect-hash table wi
 //    the reverse complement nor the canonical form.
 // Two stages: a one-bit-per-slot table of 2^20 bits that the scan kernel copies into LDS (lf_index: a fold of the m-mer's bits, no
 // multiply; built only while it stays at most half full), and a blocked Bloom filter in global memory (two bits per m-mer inside one
-// 32-bit word: < 2 % of absent m-mers pass at the sizes pf_words_log2 picks) that is asked only for what the LDS stage lets through.
+// 32-bit word: < 1 % of absent m-mers pass at the sizes pf_words_log2 picks) that is asked only for what the LDS stage lets through.
 // Only the k-mers of tiles that pass both take the exact lookup. No false negatives by construction, so results cannot change.
 NB_HD inline uint32_t pf_hash(uint64_t x) {
   const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
@@ -202,9 +202,9 @@ constexpr double LF_MAX_FILL = 0.5;                   // beyond that the LDS sta
 inline uint32_t pf_words_log2(int64_t n_canonical) {      // ~20+ bits per oriented m-mer, 4 KB .. 16 MB
   uint32_t b = 10; while (b < 22 && ((int64_t)32 << b) < 40 * n_canonical) ++b; return b;
 }
-inline int pf_stride(int k) {                         // S: the largest power of two <= 8 that leaves m = k + 1 - S >= 12 (shorter m-mers turn up by chance;
-  int s = 8; while (s > 1 && k + 1 - s < 12) s >>= 1; return s;   //  the anchor structures exist for k <= 23 only: m <= 16)
-}
+inline int pf_stride(int k) {                         // S: the largest power of two <= 8 that leaves m = k + 1 - S >= 12 (the anchor structures exist for k <= 23 only:
+  int s = 8; while (s > 1 && k + 1 - s < 12) s >>= 1; return s;   //  m <= 16). Measured (profiles/r03_tuning_notes.md): at k = 20 one in a hundred 13-mers of a foreign
+}                                                     //  read is a library 13-mer by chance and its tile takes the exact lookups, yet S = 4 (m = 17) is slower: twice the tiles
 
 // A colour (equivalence class of the graph) for the wave-per-read kernels: the span of u64 words of its bitset that can be non-zero, with
 // the first two words inline (32 bytes, two dwordx4 issued together). Bit positions are INTERNAL sequence numbers: the index builder

@@ -302,3 +302,27 @@ def test_scan_kernel_behind_the_presence_filter(built, k, loci, alleles, lds_sta
     ora = _check(strs, k, reads, L, f"scan kernel, k={k}", cfg=cfg)
     no_hit = int((ora["reason"] == 2).sum())
     assert no_hit >= 2500 and int((ora["reason"] != 2).sum()) > 200, (no_hit, len(reads))
+
+
+def test_scan_kernel_several_batches_per_wave(built):
+    """600 000 reads, 95 % of them foreign to the library: every workgroup's segment of the scan list holds several wave-batches per wave, so
+    the scan kernel's prefetch of the next batch (list entry, length, record) runs; a few hundred of the foreign reads hide one library
+    k-mer. Every read against the oracle."""
+    rng = np.random.default_rng(77)
+    _, seqs, strs, _ = library_strings(8, 20, locus_len=500, seed=320)
+    n, L, k = 600_000, 150, 20
+    codes = synth.synth_reads(seqs, n, L, seed=12, frac_random=0.95, err=0.01, n_rate=0.001)
+    lut = {c: i for i, c in enumerate("ACGT")}
+    for i in rng.integers(0, n, 400):                                       # plant a library k-mer at a random offset
+        s = strs[int(rng.integers(0, len(strs)))]
+        o = int(rng.integers(0, len(s) - k + 1)); off = int(rng.integers(0, L - k + 1))
+        codes[i, off:off + k] = [lut[c] for c in s[o:o + k]]
+    lens = rng.integers(0, L + 1, n).astype(np.uint16); lens[::2] = L
+    cfg = engine.make_config(k=k)
+    gpu = run_gpu(engine.Index(strs, k), cfg, synth.pack_codes(codes), lens, L, max_classes=1 << 18)
+    assert any(name.startswith("nb_anchor_scan_kernel") for name in gpu["kernels"]), gpu["kernels"]
+    from oracle import oracle
+    reads = ["".join("ACGTN"[c] for c in row[:ln]) for row, ln in zip(codes, lens)]
+    ora = oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=16)
+    assert_same(gpu, ora, "scan kernel, several batches per wave")
+    assert int((ora["reason"] == 2).sum()) > 400_000

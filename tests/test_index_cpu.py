@@ -201,8 +201,8 @@ def test_anchor_structures(built, with_rc, alleles, wide_table, merged, monkeypa
         assert ix.anchor_query("".join("ACGT"[c] for c in rng.integers(0, 4, K))) is None
 
 
-@pytest.mark.parametrize("k,n_loci,alleles,m", [(20, 20, 50, 13), (12, 2, 30, 12), (23, 6, 25, 16), (16, 4, 10, 13), (31, 3, 8, 24)])
-def test_presence_filter_has_no_false_negatives_and_few_false_positives(built, k, n_loci, alleles, m):
+@pytest.mark.parametrize("k,n_loci,alleles", [(20, 20, 50), (12, 2, 30), (23, 6, 25), (16, 4, 10), (20, 2, 4), (31, 3, 8)])
+def test_presence_filter_has_no_false_negatives_and_few_false_positives(built, k, n_loci, alleles):
     """The presence filter of the scan kernel (nb_internal.h: the m-mers, m = k + 1 - S, of every k-mer of the table in both orientations;
     an LDS-sized one-bit table in front of a blocked Bloom filter): every stretch of a library sequence passes, as given and reverse-
     complemented — a false negative would turn a hit into NO_HIT on the GPU; nb_index_query checks the same for each k-mer it finds — and
@@ -211,7 +211,8 @@ def test_presence_filter_has_no_false_negatives_and_few_false_positives(built, k
     ix = engine.Index(strs, k)
     if ix.filter_params() is None:
         pytest.skip("library without anchor structures")
-    assert ix.filter_params()[0] == m
+    m = ix.filter_params()[0]
+    assert k + 1 - m in (1, 2, 4, 8) and m >= min(k, 12), m                  # m = k + 1 - S, S by k and by the size of the library (pf_stride)
     comp = str.maketrans("ACGT", "TGCA")
     n = 0
     for s in strs[::3]:
@@ -221,7 +222,7 @@ def test_presence_filter_has_no_false_negatives_and_few_false_positives(built, k
             assert ix.query(km) is not None
             n += 1
         assert ix.filter_maybe(s) is True                                    # every m-mer of a whole sequence
-    assert n > 1000
+    assert n > 300
     rng = np.random.default_rng(9)
     rand = ["".join("ACGT"[c] for c in rng.integers(0, 4, m)) for _ in range(20000)]
     lib = set()
