@@ -29,7 +29,7 @@ extern "C" {
 #define NB_ERR_OVERFLOW (-4)    /* class table full: raise max_classes */
 #define NB_ERR_NOGPU (-5)       /* no usable HIP device */
 
-#define NB_ABI_VERSION 3
+#define NB_ABI_VERSION 4
 #define NB_MAX_K 31
 #define NB_MAX_POSITIONS 320    /* k-mer positions per read the kernels handle (5 wave-rounds of 64) */
 #define NB_NO_CLASS 0xFFFFFFFFu

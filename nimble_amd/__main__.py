@@ -14,7 +14,7 @@ from .report import report
 
 def build_parser():
     parser = argparse.ArgumentParser(description="nimble align")
-    parser.add_argument("-v", "--version", action="version", version="nimble_amd 0.1 (MI355X engine, C-ABI 3)")
+    parser.add_argument("-v", "--version", action="version", version="nimble_amd 0.1 (MI355X engine, C-ABI 4)")
     sub = parser.add_subparsers(title="subcommands", dest="subcommand")
 
     g = sub.add_parser("generate")

@@ -25,7 +25,7 @@ def test_header_symbols_exported(built):
 def test_python_binding_covers_header(built):
     assert sorted(_lib.SIGNATURES) == declared_functions()
     lib = _lib.lib()
-    assert lib.nb_version() == 3
+    assert lib.nb_version() == 4
     assert lib.nb_packed_stride_words(150) == 8          # 5 base words + 3 N-mask words = 64 B per 150-bp read
     assert lib.nb_kernel_name(150, 20, 1000, 0) == b"nb_align_se_kernel<3, 1, true, true>"
     assert lib.nb_kernel_name(91, 20, 1000, 0) == b"nb_align_se_kernel<2, 1, false, true>"
