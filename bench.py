@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--alleles", type=int, default=None)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--foreign", type=float, default=None, help="fraction of uniform random reads in the synthetic batch (default: synth's 0.10); sweeps only")
+    ap.add_argument("--mismatches", type=int, default=0, help="num_mismatches of the library config (default 0: the metric's configuration); sweeps only")
     ap.add_argument("--err", type=float, default=None, help="substitution rate of the library-derived reads (default: synth's 0.01); sweeps only")
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="upper bound of the reads timed on the CPU baseline (rank 0, N=1 only); the "
                     "actual sample is sized from a calibration slice so that the timed call runs about --cpu-seconds")
@@ -209,7 +210,7 @@ def main():
     t_gen = time.time() - t0
     out_class = torch.empty(n, dtype=torch.int32, device=dev)
     out_info = torch.empty(n, dtype=torch.int32, device=dev)
-    cfg = engine.make_config(k=args.k)
+    cfg = engine.make_config(k=args.k, num_mismatches=args.mismatches)
     stream = torch.cuda.current_stream(dev)
 
     def step():

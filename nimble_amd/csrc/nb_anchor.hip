@@ -61,6 +61,7 @@ struct AnchorHead {
   uint32_t* retry_state; long long retry_seg;        // the walk of a straggler as it stood at the hand-over (RetryShape<NR, NW>::DW dwords per list entry); entries per workgroup segment
   const uint32_t* pfilter; uint32_t pf_wbits;        // presence filter over the oriented k-mers of the table (nb_internal.h): 2^pf_wbits words
   const uint32_t* lfilter;                           // its LDS-sized first stage (2^20 bits), or null (library too large for it to discriminate)
+  const uint32_t* text_rint; int M;                  // num_mismatches > 0: r_internal bit of every text k-mer, the per-read budget of tolerated mismatches (SPEC 3)
 };
 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
@@ -71,7 +72,7 @@ struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
 // inside a verified run. One bit per lattice point: 64 NR positions hold at most 22 NR of them (one word up to NR = 3).
 template <int NR> struct CoverShape { static constexpr int LW = NR <= 3 ? 1 : 2; };
 __device__ __forceinline__ uint32_t div3(uint32_t x) { return (x * 0xAAABu) >> 17; }          // floor(x / 3), x < 98 304
-template <int NR, int NW> struct RetryShape { static constexpr int DW = (8 + 2 * NW + 2 * CoverShape<NR>::LW + 3) & ~3; };
+template <int NR, int NW> struct RetryShape { static constexpr int DW = (11 + 2 * NW + 2 * CoverShape<NR>::LW + 3) & ~3; };  // (+ patches (2 dwords), cv_from | ended-by-room << 16; mm in d0 bits 27..31)
 
 #ifdef NB_ANCHOR_PROF   // phase clock for tuning (-DNB_ANCHOR_PROF through NB_EXTRA_HIPCC_FLAGS): cycles per phase summed over waves, see scripts/anchor_phases.py
 __device__ unsigned long long g_anchor_prof[16];
@@ -340,6 +341,13 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
 #pragma unroll
       for (int wi = 0; wi < LW; ++wi) cover[wi] = ((uint64_t)rs[B + 7 + 2 * wi] << 32) | rs[B + 6 + 2 * wi];
     }
+    // tolerated mismatches (num_mismatches = h.M > 0, SPEC 3): while the read follows the text, a base that differs (or an N) is passed over if
+    // the text k-mer before it is r_internal — its unique right extension is the text's next base — and the budget allows. The read's own
+    // k-mers over that base were never looked up: their seed-scan positions stay unsettled for the other orientation (cv_from).
+    int mm = 0, cv_from = 0; bool er = false;      // mismatches used; first position of the run whose k-mers equal the read's; last run ended for lack of room
+    uint64_t patches = 0;                          // the four latest bases passed over: position (9 bits) | read base XOR text base << 9 | 1 << 15 each (the
+                                                   // walk goes on from the corrected k-mer: the next STEP lookups see the text's base there, SPEC 3's succ(x, u))
+    if (listed && active) { mm = (int)(rs[0] >> 27); cv_from = (int)(rs[RDW - 1] & 0xFFFFu); er = ((rs[RDW - 1] >> 16) & 1u) != 0; patches = ((uint64_t)rs[RDW - 2] << 32) | rs[RDW - 3]; }
     uint64_t busy;
     while ((busy = __ballot(mode != DONE)) != 0) {
       if (h.retry_out && rounds >= h.retry_rounds && __popcll(busy) <= h.retry_lanes) {   // the few lanes left hold the whole wave: second pass
@@ -355,7 +363,8 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
           uint32_t d[RDW];
 #pragma unroll
           for (int j = 0; j < RDW; ++j) d[j] = 0u;
-          d[0] = (uint32_t)(cov & 0xFFFF) | ((fl & 0xFFu) << 16) | ((uint32_t)mode << 24) | ((rcf ? 1u : 0u) << 26);
+          d[0] = (uint32_t)(cov & 0xFFFF) | ((fl & 0xFFu) << 16) | ((uint32_t)mode << 24) | ((rcf ? 1u : 0u) << 26) | ((uint32_t)mm << 27);
+          d[RDW - 1] = ((uint32_t)cv_from & 0xFFFFu) | ((er ? 1u : 0u) << 16); d[RDW - 3] = (uint32_t)patches; d[RDW - 2] = (uint32_t)(patches >> 32);
           d[1] = (lo & 0xFFFFu) | (p_w0 << 16);
           d[2] = (uint32_t)a0; d[3] = (uint32_t)(a0 >> 32);
           if (NW > 1) { d[B - 2] = (uint32_t)a1; d[B - 1] = (uint32_t)(a1 >> 32); }
@@ -379,6 +388,14 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         const bool step = mode == STEP;
         const int q = act ? (step ? pos - K + 1 : pos) : 0;           // k-mer position of this round's lookup
         uint64_t w; uint32_t nn; R.get32(q - (step ? 1 : 0), w, nn);  // (STEP: one base earlier, for the left-extension test; q >= 1 there)
+        if (h.M > 0 && __ballot(step && patches != 0ull)) {            // STEP continues from the CORRECTED k-mer: bases passed over take the text's value
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t e = (uint32_t)(patches >> (16 * i)) & 0xFFFFu;
+            const int dd = (int)(e & 0x1FFu) - (q - 1);
+            if (step && (e & 0x8000u) && dd >= 0 && dd <= K) { w ^= (uint64_t)((e >> 9) & 3u) << (2 * dd); nn &= ~(1u << dd); }
+          }
+        }
         const uint32_t pb = (uint32_t)w & 3u;
         const uint64_t x = (step ? (w >> 2) : w) & kmask;
         const bool valid = act && (((step ? (nn >> 1) : nn) & nkmask) == 0);
@@ -414,13 +431,14 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
             fl |= F_LEXT; ls_q = q; ls_t = k.e.z; ls_room = (int)((k.e.w >> 8) & 0x7Fu);
           }
           fl = (fl & ~F_STEP) | (step ? F_STEP : 0u) | F_SEEDED;
-          run_t = k.e.z; run_w0 = k.e.w >> 16; run_q = q; steps = 0;
+          run_t = k.e.z; run_w0 = k.e.w >> 16; run_q = q; steps = 0; cv_from = q; er = false;
           fl |= (k.e.w & ANCHOR_WIDE) ? F_SLOW : 0u;                          // a component wider than the sparse table's entries: wave-per-read kernel
           const int room = (int)(k.e.w & 0xFFu), rem = L - (q + K);
           maxsteps = room < rem ? room : rem;
           mode = EXT;
         } else if (act) {
           { const uint32_t j = div3((uint32_t)(q + 3 - res)); if ((int)(3u * j) == q + 3 - res) cover_set((int)j - 1, (int)j - 1); }     // (a looked-up position on the lattice)
+          if (step && h.M > 0 && er && mm < h.M) fl |= F_SLOW;              // (the run ended for lack of room, not at a mismatch: whether SPEC 3 would pass over this base is not known here)
           if (step) mode = pos > last ? DONE : SEEK;                          // the walk broke at base pos: seed scan from there (SPEC §3)
           else { pos += 3; mode = pos > last ? DONE : SEEK; }
         }
@@ -445,13 +463,27 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
           const int fn = sn ? __builtin_ctz(sn) : 32;
           const int m = fm < fn ? fm : fn;
           const int room_left = maxsteps - steps;
+          uint64_t rw = 0;                                                    // bit i: the text k-mer at run_t + steps + i is r_internal
+          if (h.M > 0) { const uint32_t tx = run_t + (uint32_t)steps; const uint32_t* rq = h.text_rint + (tx >> 5); rw = ((((uint64_t)rq[1]) << 32) | rq[0]) >> (tx & 31u); }
           steps += m < room_left ? m : room_left;
           fin = (m < 32) || steps >= maxsteps;
+          if (h.M > 0 && m < 32 && m < room_left && mm < h.M && ((rw >> m) & 1ull)) {   // pass over the base at run_q + K + steps
+            cover_set((int)div3((uint32_t)(cv_from - res + 2 + 3)) - 1, (int)div3((uint32_t)(run_q + steps - res + 3)) - 1);
+            cv_from = run_q + steps + K + 1;                                  // (the read's k-mers over that base are not the text's)
+            { const int b_ = run_q + K + steps;                                 // the base passed over: remember what the text has there
+              const uint32_t old_ = (uint32_t)(patches >> 48) & 0xFFFFu;
+              if ((old_ & 0x8000u) && b_ - (int)(old_ & 0x1FFu) <= K) fl |= F_SLOW;   // (a fifth one within k bases: the list holds four)
+              const uint32_t delta = (uint32_t)((sw ^ tw) >> (2 * m)) & 3u;
+              patches = (patches << 16) | (uint64_t)(0x8000u | (delta << 9) | ((uint32_t)b_ & 0x1FFu)); }
+            steps += 1; mm += 1;
+            fin = steps >= maxsteps;
+          }
         }
         if (fin) {                                                            // the run [run_q, run_q + steps] is complete
           cov += ((fl & F_STEP) ? 1 : K) + steps;
           p_t = run_t; p_n = (uint32_t)steps + 1u; p_w0 = run_w0;
-          cover_set((int)div3((uint32_t)(run_q - res + 2 + 3)) - 1, (int)div3((uint32_t)(run_q + steps - res + 3)) - 1);   // lattice points inside [run_q, run_q + steps]
+          er = steps >= maxsteps;
+          cover_set((int)div3((uint32_t)(cv_from - res + 2 + 3)) - 1, (int)div3((uint32_t)(run_q + steps - res + 3)) - 1);   // lattice points inside [cv_from, run_q + steps]
           pos = run_q + K + steps;                                            // the base the run stopped at
           mode = pos >= L ? DONE : STEP;
         }
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
     // then stops at a base that no sequence continues with (the sequencing error that killed the earlier seeds), at an N, or at its own
     // start. One comparison, one lookup (the left-extension mask of the k-mer at which the comparison stopped), one AND; if some sequence
     // does continue there, the read stays with the wave-per-read kernel. ----
-    if (__ballot((fl & F_REDO) == F_LEXT)) {
+    if (h.M == 0 && __ballot((fl & F_REDO) == F_LEXT)) {                      // (with tolerated mismatches the left extension is the wave-per-read kernel's)
       const bool le = (fl & F_REDO) == F_LEXT;
       int lm = 0; bool verify = false, solved = false;
       if (le) {
@@ -1055,12 +1087,12 @@ bool anchor_pilots_in_lds(const nb_ctx* c, int max_len) {
   return anchor_lds_bytes(c, max_len, &w, &plds) > 0 && plds;
 }
 
-static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads, const uint16_t* lens, int max_len, long long n, bool plds, MateRes* mate_out) {
+static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads, const uint16_t* lens, int max_len, long long n, bool plds, MateRes* mate_out, int num_mismatches) {
   const int nwb = (max_len + 31) / 32, nwn = (nwb + 1) >> 1;
   return AnchorHead{c->d_atable, c->d_akeys, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
                     (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out,
-                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, c->d_pfilter, c->pf_wbits, c->d_lfilter};
+                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, c->d_pfilter, c->pf_wbits, c->d_lfilter, c->d_text_rint, num_mismatches};
 }
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {
@@ -1071,7 +1103,7 @@ int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, con
   if (!c->d_lane_tail) NB_HIP(hipMalloc((void**)&c->d_lane_tail, sizeof(LaneTail)));
   LaneTail t{c->ct, a, ll, ix.W};
   NB_HIP(hipMemcpyAsync(c->d_lane_tail, &t, sizeof t, hipMemcpyHostToDevice, s));
-  const AnchorHead h = make_head(c, ix.K, ix.W, a.reads, a.lens, a.max_len, a.n, plds, nullptr);
+  const AnchorHead h = make_head(c, ix.K, ix.W, a.reads, a.lens, a.max_len, a.n, plds, nullptr, a.num_mismatches);
   return launch_anchor_nr<false>(c, nr, h, (const LaneTail*)c->d_lane_tail, waves, lds, plds, s);
 }
 
@@ -1091,7 +1123,7 @@ int launch_anchor_pairs(nb_ctx* c, const DevIndex& ix, const BatchArgs& a, const
     const int64_t lds = anchor_lds_bytes(c, max_len, &waves, &plds);
     if (lds <= 0) { set_error("launch_anchor_pairs: shape does not fit"); return NB_ERR_UNSUPPORTED; }
     const int positions = max_len - ix.K + 1, nr = positions < 1 ? 1 : (positions + 63) / 64;
-    const AnchorHead h = make_head(c, ix.K, ix.W, m ? a.mates : a.reads, m ? a.mate_lens : a.lens, max_len, a.n, plds, mr + (size_t)m * (size_t)a.n);
+    const AnchorHead h = make_head(c, ix.K, ix.W, m ? a.mates : a.reads, m ? a.mate_lens : a.lens, max_len, a.n, plds, mr + (size_t)m * (size_t)a.n, a.num_mismatches);
     if (m) NB_HIP(hipMemsetAsync(ll.counters, 0, 4, s));                    // the scan list of the second mate starts empty
     const int rc = launch_anchor_nr<true>(c, nr, h, dt, waves, lds, plds, s);
     if (rc != NB_OK) return rc;

@@ -382,6 +382,7 @@ struct nb_ctx {
   uint32_t* d_retry_list = nullptr; uint32_t* d_retry_counts = nullptr; int64_t retry_cap = 0; uint32_t* d_retry_state = nullptr; int retry_state_dw = 0;   // stragglers of the anchor kernel's first pass (nb_anchor.hip)
   bool anchor_retry_ran = false;   // the last launch_anchor / launch_anchor_pairs ran the second pass (reported in last_kernels)
   uint32_t* d_akeys = nullptr;     // key words of d_atable alone (nb_internal.h, akeys)
+  uint32_t* d_text_rint = nullptr; // r_internal bit of every text k-mer (anchor walk with num_mismatches > 0)
   uint32_t* d_lfilter = nullptr;   // first stage of the presence filter (copied to LDS by the scan kernel), null if not built
   uint32_t* d_pfilter = nullptr; uint32_t pf_wbits = 0; int pf_m = 0, pf_s = 1;   // presence filter of the anchor kernels (nb_internal.h)
   nb::AEntry* d_atable = nullptr; uint32_t* d_text = nullptr; uint64_t* d_sparse = nullptr; long long text_len = 0; bool has_anchor = false; int anchor_nw = 1;   // anchor structures (nb_anchor.hip)

@@ -261,6 +261,7 @@ struct HostIndex {
   std::vector<uint32_t> akeys;        // the key words of atable alone (4 bytes per slot): what a presence / strand test needs (probes, the
                                       // other-orientation check, the scan kernel) from an array a quarter the size of the table
   std::vector<uint64_t> sparse;       // ANCHOR_LEVELS * text_len words
+  std::vector<uint32_t> text_rint;    // one bit per text position: r_internal of the k-mer that starts there (tolerated mismatches of the anchor walk)
   std::vector<uint32_t> pfilter;      // presence filter over the oriented k-mers of the table (above): 2^pf_wbits words
   uint32_t pf_wbits = 0;
   int pf_m = 0, pf_s = 1;             // m-mer length of the filters, stride S = k + 1 - m of the tests

@@ -1163,7 +1163,7 @@ int32_t nb_ctx_destroy(nb_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_slots); (void)hipFree(c->d_ctable); (void)hipFree(c->d_desc); (void)hipFree(c->d_packed); (void)hipFree(c->ct.keys); (void)hipFree(c->ct.ids); (void)hipFree(c->ct.rows);
   (void)hipFree(c->ct.counts); (void)hipFree(c->ct.spans); (void)hipFree(c->d_lists); (void)hipFree(c->d_list_counters); (void)hipFree(c->d_scan_counts); (void)hipFree(c->d_retry_list); (void)hipFree(c->d_retry_counts); (void)hipFree(c->d_retry_state); (void)hipFree(c->d_redo_reads); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); (void)hipFree(c->d_redo_mates); (void)hipFree(c->d_redo_mate_lens); (void)hipFree(c->d_mate_res); (void)hipFree(c->d_lane_tail); if (c->h_stage) { if (c->h_stage_pinned) (void)hipHostFree(c->h_stage); else std::free(c->h_stage); } if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-  (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
+  (void)hipFree(c->d_ph_table); (void)hipFree(c->d_ph_pilots); (void)hipFree(c->d_atable); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); (void)hipFree(c->d_text_rint); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->ct.n_classes); (void)hipFree(c->ct.err); (void)hipFree(c->ct.reasons); (void)hipFree(c->d_pct); (void)hipFree(c->d_ct);
   delete c; return NB_OK;
 }
 
@@ -1187,8 +1187,8 @@ int32_t nb_index_stats(const nb_index* ix, nb_index_stats_t* s) {
   s->n_seqs = h.n_seqs; s->n_kmers = h.n_kmers; s->n_canonical = h.n_canonical; s->table_slots = h.compact ? (int64_t)h.ctable.size() * 2 : (int64_t)h.buckets.size() * SLOTS_PER_BUCKET;
   s->n_colours = (int64_t)h.eq_sizes.size(); s->words_per_row = h.words;
   s->table_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket)); s->compact = h.compact ? 1 : 0; s->words_internal = h.words_dev; s->ph_table_bytes = (int64_t)(h.ph_table.size() * sizeof(PHEntry)); s->ph_pilot_bytes = (int64_t)h.ph_pilots.size();
-  s->anchor_bytes = (int64_t)(h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8);
-  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
+  s->anchor_bytes = (int64_t)(h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text_rint.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8);
+  s->device_bytes = s->table_bytes + (int64_t)(h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text_rint.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); s->k = h.k; s->uploaded = h.uploaded;
   return NB_OK;
 }
 
@@ -1291,7 +1291,7 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
     NB_HIP(hipMemcpy(c->d_ph_table, h.ph_table.data(), h.ph_table.size() * sizeof(PHEntry), hipMemcpyHostToDevice));
     NB_HIP(hipMemcpy(c->d_ph_pilots, h.ph_pilots.data(), h.ph_pilots.size(), hipMemcpyHostToDevice));
   }
-  (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr; c->d_pfilter = nullptr; c->d_lfilter = nullptr;
+  (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); (void)hipFree(c->d_text_rint); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr; c->d_pfilter = nullptr; c->d_lfilter = nullptr; c->d_text_rint = nullptr;
   c->has_anchor = h.has_anchor; c->pf_wbits = h.pf_wbits; c->pf_m = h.pf_m; c->pf_s = h.pf_s; c->text_len = h.text_len; c->anchor_nw = h.anchor_nw;
   if (h.has_anchor) {
     // (the sparse table is the one large piece — 8 or 16 bytes x 8 levels per library base: if it does not fit next to the caller's
@@ -1301,11 +1301,12 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
                      hipMalloc((void**)&c->d_sparse, h.sparse.size() * 8) == hipSuccess;
     if (!got) {
       (void)hipGetLastError();
-      (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr; c->d_pfilter = nullptr; c->d_lfilter = nullptr;
+      (void)hipFree(c->d_atable); (void)hipFree(c->d_text); (void)hipFree(c->d_sparse); (void)hipFree(c->d_akeys); (void)hipFree(c->d_pfilter); (void)hipFree(c->d_lfilter); (void)hipFree(c->d_text_rint); c->d_atable = nullptr; c->d_text = nullptr; c->d_sparse = nullptr; c->d_akeys = nullptr; c->d_pfilter = nullptr; c->d_lfilter = nullptr; c->d_text_rint = nullptr;
       c->has_anchor = false;
     } else {
       NB_HIP(hipMemcpy(c->d_akeys, h.akeys.data(), h.akeys.size() * 4, hipMemcpyHostToDevice));
       NB_HIP(hipMemcpy(c->d_pfilter, h.pfilter.data(), h.pfilter.size() * 4, hipMemcpyHostToDevice));
+      NB_HIP(hipMalloc((void**)&c->d_text_rint, h.text_rint.size() * 4)); NB_HIP(hipMemcpy(c->d_text_rint, h.text_rint.data(), h.text_rint.size() * 4, hipMemcpyHostToDevice));
       if (!h.lfilter.empty()) { NB_HIP(hipMalloc((void**)&c->d_lfilter, h.lfilter.size() * 4)); NB_HIP(hipMemcpy(c->d_lfilter, h.lfilter.data(), h.lfilter.size() * 4, hipMemcpyHostToDevice)); }
       NB_HIP(hipMemcpy(c->d_atable, h.atable.data(), h.atable.size() * sizeof(AEntry), hipMemcpyHostToDevice));
       NB_HIP(hipMemcpy(c->d_text, h.text.data(), h.text.size() * 4, hipMemcpyHostToDevice));
@@ -1326,7 +1327,7 @@ int32_t nb_index_upload(nb_ctx* c, nb_index* ix) {
   if (!c->d_ct) NB_HIP(hipMalloc((void**)&c->d_ct, sizeof(DevClasses)));
   NB_HIP(hipMemcpy(c->d_ct, &c->ct, sizeof(DevClasses), hipMemcpyHostToDevice));
   c->hash = h.hash; c->W = h.words_dev; c->W_ext = h.words; c->inv_perm = h.inv_perm; c->K = h.k; c->n_seqs = h.n_seqs;
-  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); h.uploaded = 1;
+  c->index_bytes = (int64_t)(h.buckets.size() * sizeof(Bucket) + h.ctable.size() * sizeof(CBucket) + h.desc.size() * sizeof(ColDesc) + h.packed.size() * 8 + h.ph_table.size() * sizeof(PHEntry) + h.ph_pilots.size() + h.atable.size() * sizeof(AEntry) + h.akeys.size() * 4 + h.pfilter.size() * 4 + h.lfilter.size() * 4 + h.text_rint.size() * 4 + h.text.size() * 4 + h.sparse.size() * 8); h.uploaded = 1;
   return nb_results_reset(c, nullptr);
 }
 
@@ -1413,7 +1414,9 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   // anchor-extend kernel (nb_anchor.hip) when the index carries the anchor structures: far fewer lookups per read; else the lane-per-read
   // kernels of nb_lane.hip (first level of the table must fit LDS)
   const bool use_anchor = c->has_anchor && !(anchor_env && anchor_env[0] == '0') && anchor_fits(c, max_len);
-  if (!d_mates && cfg->num_mismatches == 0 && c->has_ph && positions >= 1 && n < (1ll << 31) && !(lane_env && lane_env[0] == '0') &&
+  // (tolerated mismatches, num_mismatches 1 .. 31: the anchor kernels only — they pass over a base while they follow the text; nb_anchor.hip)
+  const bool mm_ok = cfg->num_mismatches == 0 || (use_anchor && cfg->num_mismatches <= 31 && !(std::getenv("NB_ANCHOR_MM") && std::getenv("NB_ANCHOR_MM")[0] == '0'));
+  if (!d_mates && mm_ok && c->has_ph && positions >= 1 && n < (1ll << 31) && !(lane_env && lane_env[0] == '0') &&
       (use_anchor || lane_lds_bytes(c, max_len, &lane_wpb) > 0)) {
     const int64_t stride = a.stride;
     if (c->lists_cap < n) {
@@ -1439,11 +1442,17 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
       }
       else std::snprintf(buf, sizeof buf, "nb_lane_kernel<%d, 0>;nb_lane_kernel<%d, 1>", nr > 5 ? 5 : nr, nr > 5 ? 5 : nr);
       c->last_kernels = buf; }
+    const std::string buf_names = c->last_kernels;
     rc = launch_lane_gather(c, a, ll, c->d_redo_reads, c->d_redo_lens, s); if (rc != NB_OK) return rc;
     BatchArgs b = a;
     b.reads = c->d_redo_reads; b.lens = a.lens ? c->d_redo_lens : nullptr; b.n_dev = c->d_list_counters + 1;
     b.out_class = a.out_class ? c->d_redo_out : nullptr; b.out_info = a.out_info ? c->d_redo_out + c->lists_cap : nullptr;
     b.out_cov = a.out_cov ? reinterpret_cast<uint64_t*>(c->d_redo_out + 2 * c->lists_cap) : nullptr;
+    if (cfg->num_mismatches > 0) {                                            // the redo reads of a run with tolerated mismatches: the LDS-staged mapper
+      if (c->compact) rc = (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, false, ix, b, s) : dispatch_general<4, true>(c, nr, positions, false, ix, b, s);
+      else rc = (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, false, ix, b, s) : dispatch_general<4, false>(c, nr, positions, false, ix, b, s);
+      c->last_kernels = std::string(buf_names) + ";" + c->last_kernels;
+    } else
     if (c->compact) rc = (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, b, s) : dispatch_se<4, true>(c, nr, positions, ix, b, s);
     else rc = (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, b, s) : dispatch_se<4, false>(c, nr, positions, ix, b, s);   // (anchors next to the wide table)
     if (rc != NB_OK) return rc;
@@ -1452,7 +1461,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   }
   // Paired templates in exact mode, index with anchor structures: each mate through the anchor kernels (raw alignments), SPEC §4 for the
   // pair in nb_anchor_pair_kernel; pairs it cannot settle are gathered and go through the general kernel below (nb_anchor.hip).
-  if (d_mates && cfg->num_mismatches == 0 && c->has_anchor && !(anchor_env && anchor_env[0] == '0') && !(lane_env && lane_env[0] == '0') && n < (1ll << 31) &&
+  if (d_mates && (cfg->num_mismatches == 0 || (cfg->num_mismatches <= 31 && !(std::getenv("NB_ANCHOR_MM") && std::getenv("NB_ANCHOR_MM")[0] == '0'))) && c->has_anchor && !(anchor_env && anchor_env[0] == '0') && !(lane_env && lane_env[0] == '0') && n < (1ll << 31) &&
       max_len >= c->K && mate_max_len >= c->K && anchor_fits(c, max_len) && anchor_fits(c, mate_max_len)) {
     if (c->lists_cap < n) {
       (void)hipFree(c->d_lists); (void)hipFree(c->d_redo_lens); (void)hipFree(c->d_redo_out); c->d_lists = nullptr; c->d_redo_lens = nullptr; c->d_redo_out = nullptr;
@@ -1486,8 +1495,9 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     b.n_dev = c->d_list_counters + 1;
     b.out_class = a.out_class ? c->d_redo_out : nullptr; b.out_info = a.out_info ? c->d_redo_out + c->lists_cap : nullptr;
     b.out_cov = a.out_cov ? reinterpret_cast<uint64_t*>(c->d_redo_out + 2 * c->lists_cap) : nullptr;
-    if (c->compact) rc = (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, true, ix, b, s) : dispatch_general<4, true>(c, nr, positions, true, ix, b, s);
-    else rc = (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, true, ix, b, s) : dispatch_general<4, false>(c, nr, positions, true, ix, b, s);
+    const bool exact_redo = cfg->num_mismatches == 0;
+    if (c->compact) rc = (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, exact_redo, ix, b, s) : dispatch_general<4, true>(c, nr, positions, exact_redo, ix, b, s);
+    else rc = (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, exact_redo, ix, b, s) : dispatch_general<4, false>(c, nr, positions, exact_redo, ix, b, s);
     if (rc != NB_OK) return rc;
     c->last_kernels = "nb_anchor_kernel<mates>;nb_anchor_scan_kernel<mates>;nb_anchor_pair_kernel;" + c->last_kernels;
     BatchArgs sc = a; sc.n = c->lists_cap;

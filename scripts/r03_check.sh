@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick parity + timing on the GPU box: anchor parity tests, then bench lines (c2 default, all-foreign batch): bash scripts/r03_check.sh
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_anchor_gpu.py tests/test_align_gpu.py -x -q -m gpu > gpurun_out/check_tests.log 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests/test_anchor_gpu.py tests/test_align_gpu.py tests/test_general_gpu.py -x -q -m gpu > gpurun_out/check_tests.log 2>&1; rc=$?
 tail -n 4 gpurun_out/check_tests.log
 [ $rc -ne 0 ] && { echo "tests failed rc=$rc"; exit $rc; }
 one() { label=$1; shift
@@ -13,6 +13,8 @@ ENVX=NB_ANCHOR_DBG=16 one c2_nofilter_in_tail
 one c2_foreign --foreign 1.0
 one c2_foreign50 --foreign 0.5
 one c3 --config c3 --steps 3
+one c2_mm2 --mismatches 2
+ENVX=NB_ANCHOR_MM=0 one c2_mm2_general --mismatches 2 --reads 2000000
 one c5 --config c5 --steps 3
 bash scripts/r03_trace.sh check_trace
 bash scripts/r03_trace.sh check_trace_foreign --foreign 1.0

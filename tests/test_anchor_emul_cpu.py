@@ -49,12 +49,28 @@ def _run(emul, tmp_path, strs, k, reads, max_len, cfg, max_redo_frac):
         retried = int(log.split("retried ")[1].split(",")[0])
         if retry in (0, None):                                    # (after two or five rounds a scenario of short reads may have nobody left walking)
             assert (retried > 0) == (retry is not None and len(reads) > 50), log
+    # tolerated mismatches (num_mismatches 1 and 3): the walk passes over a base while it follows the text and goes on from the corrected
+    # k-mer; what the kernels finish themselves must equal the oracle run with the same budget (first pass, and resumed after two rounds)
+    for mm in (1, 3):
+        cfg_m = engine.make_config(**{**_cfg_kwargs(cfg), "num_mismatches": mm})
+        ora_m = oracle.OracleIndex(strs, k).align_strs(cfg_m, reads, n_threads=4)
+        for retry in (None, 2):
+            got_m, log_m = _emulate(emul, inp, out, retry, mm=mm)
+            _compare(got_m, ora_m, min(1.0, max_redo_frac + 0.15), log_m)
     return got, ora, log
 
 
-def _emulate(emul, inp, out, retry):
+def _cfg_kwargs(cfg):
+    return dict(k=cfg.k, score_threshold=cfg.score_threshold, score_filter=cfg.score_filter, score_percent=cfg.score_percent,
+                discard_multiple_matches=bool(cfg.discard_multiple_matches), strand_filter=int(cfg.strand_filter))
+
+
+def _emulate(emul, inp, out, retry, mm=0):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     env.pop("NB_EMUL_RETRY", None)
+    env.pop("NB_EMUL_MM", None)
+    if mm:
+        env["NB_EMUL_MM"] = str(mm)
     if retry is not None:
         env["NB_EMUL_RETRY"] = str(retry)
     r = subprocess.run([emul, inp, out], capture_output=True, text=True, timeout=900, env=env)

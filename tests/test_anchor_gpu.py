@@ -326,3 +326,39 @@ def test_scan_kernel_several_batches_per_wave(built):
     ora = oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=16)
     assert_same(gpu, ora, "scan kernel, several batches per wave")
     assert int((ora["reason"] == 2).sum()) > 400_000
+
+
+@pytest.mark.parametrize("M,kw", [(1, dict()), (2, dict(discard_multiple_matches=True)), (3, dict(strand_filter="fiveprime", score_percent=0.8)), (31, dict())])
+def test_tolerated_mismatches_on_the_anchor_path(built, M, kw, monkeypatch):
+    """num_mismatches > 0 (SPEC 3: a base that differs is passed over where the graph has one way on, M times per read) on the anchor kernels:
+    while the read follows the text the walk passes over the base if the text k-mer before it is r_internal and goes on from the CORRECTED
+    k-mer (the next STEP lookups see the text's base there); the read's own k-mers over that base stay unsettled for the other orientation;
+    left extensions and runs that end for lack of room go to the mismatch-tolerant wave-per-read kernel. Single-end (ragged, Ns, a straggler
+    pass that resumes walks with their budget and corrections) and paired, every read against the oracle; NB_ANCHOR_MM=0 (the general kernel
+    alone) must say the same."""
+    from oracle import oracle
+    from tests.test_general_gpu import synth_pairs
+    monkeypatch.setenv("NB_ANCHOR_RETRY_MIN", "0"); monkeypatch.setenv("NB_ANCHOR_RETRY_ROUNDS", "4")
+    _, seqs, strs, _ = library_strings(12, 30)
+    codes = synth.synth_reads(seqs, 40000, 150, seed=50 + M, err=0.015, n_rate=0.003)
+    rng = np.random.default_rng(M)
+    lens = rng.integers(0, 151, codes.shape[0]).astype(np.uint16); lens[::3] = 150
+    cfg = engine.make_config(num_mismatches=M, **kw)
+    index = engine.Index(strs, 20)
+    gpu = run_gpu(index, cfg, synth.pack_codes(codes), lens, 150)
+    assert gpu["kernels"][0].startswith("nb_anchor_kernel") and any(n.startswith("nb_align_general_kernel") for n in gpu["kernels"]), gpu["kernels"]
+    reads = ["".join("ACGTN"[c] for c in row[:L]) for row, L in zip(codes, lens)]
+    ox = oracle.OracleIndex(strs, 20)
+    ora = ox.align_strs(cfg, reads, n_threads=8)
+    assert_same(gpu, ora, f"single-end, num_mismatches {M}")
+    exact = ox.align_strs(engine.make_config(**kw), reads, n_threads=8)
+    assert int((np.asarray(ora["score"]) != np.asarray(exact["score"])).sum()) > 5000            # (the budget matters for these reads)
+    c1, c2 = synth_pairs(seqs, 8000, 100, 91, seed=9 + M)
+    gpu = run_gpu(index, cfg, synth.pack_codes(c1), None, 100, mate_words=synth.pack_codes(c2), mate_max_len=91)
+    assert gpu["kernels"][0].startswith("nb_anchor_kernel<mates>"), gpu["kernels"]
+    b1, o1 = synth.reads_to_ascii(c1); b2, o2 = synth.reads_to_ascii(c2)
+    assert_same(gpu, ox.align(cfg, b1, o1, b2, o2, n_threads=8), f"pairs, num_mismatches {M}")
+    monkeypatch.setenv("NB_ANCHOR_MM", "0")
+    gpu = run_gpu(index, cfg, synth.pack_codes(codes[:8000]), lens[:8000], 150)
+    assert gpu["kernels"][0].startswith("nb_align_general_kernel"), gpu["kernels"]
+    assert_same(gpu, ox.align_strs(cfg, reads[:8000], n_threads=8), f"general kernel alone, num_mismatches {M}")
