@@ -388,12 +388,13 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         const bool step = mode == STEP;
         const int q = act ? (step ? pos - K + 1 : pos) : 0;           // k-mer position of this round's lookup
         uint64_t w; uint32_t nn; R.get32(q - (step ? 1 : 0), w, nn);  // (STEP: one base earlier, for the left-extension test; q >= 1 there)
+        int pmax = -1;                                                 // the last corrected base inside the k-mer looked up (STEP with corrections)
         if (h.M > 0 && __ballot(step && patches != 0ull)) {            // STEP continues from the CORRECTED k-mer: bases passed over take the text's value
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const uint32_t e = (uint32_t)(patches >> (16 * i)) & 0xFFFFu;
-            const int dd = (int)(e & 0x1FFu) - (q - 1);
-            if (step && (e & 0x8000u) && dd >= 0 && dd <= K) { w ^= (uint64_t)((e >> 9) & 3u) << (2 * dd); nn &= ~(1u << dd); }
+            const int pp = (int)(e & 0x1FFu), dd = pp - (q - 1);
+            if (step && (e & 0x8000u) && dd >= 0 && dd <= K) { w ^= (uint64_t)((e >> 9) & 3u) << (2 * dd); nn &= ~(1u << dd); if (dd >= 1 && pp > pmax) pmax = pp; }
           }
         }
         const uint32_t pb = (uint32_t)w & 3u;
@@ -431,13 +432,13 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
             fl |= F_LEXT; ls_q = q; ls_t = k.e.z; ls_room = (int)((k.e.w >> 8) & 0x7Fu);
           }
           fl = (fl & ~F_STEP) | (step ? F_STEP : 0u) | F_SEEDED;
-          run_t = k.e.z; run_w0 = k.e.w >> 16; run_q = q; steps = 0; cv_from = q; er = false;
+          run_t = k.e.z; run_w0 = k.e.w >> 16; run_q = q; steps = 0; cv_from = pmax >= q ? pmax + 1 : q; er = false;   // (k-mers over a corrected base are not the read's own)
           fl |= (k.e.w & ANCHOR_WIDE) ? F_SLOW : 0u;                          // a component wider than the sparse table's entries: wave-per-read kernel
           const int room = (int)(k.e.w & 0xFFu), rem = L - (q + K);
           maxsteps = room < rem ? room : rem;
           mode = EXT;
         } else if (act) {
-          { const uint32_t j = div3((uint32_t)(q + 3 - res)); if ((int)(3u * j) == q + 3 - res) cover_set((int)j - 1, (int)j - 1); }     // (a looked-up position on the lattice)
+          if (pmax < 0) { const uint32_t j = div3((uint32_t)(q + 3 - res)); if ((int)(3u * j) == q + 3 - res) cover_set((int)j - 1, (int)j - 1); }     // (a looked-up position on the lattice; not if a corrected k-mer was looked up instead of the read's)
           if (step && h.M > 0 && er && mm < h.M) fl |= F_SLOW;              // (the run ended for lack of room, not at a mismatch: whether SPEC 3 would pass over this base is not known here)
           if (step) mode = pos > last ? DONE : SEEK;                          // the walk broke at base pos: seed scan from there (SPEC §3)
           else { pos += 3; mode = pos > last ? DONE : SEEK; }

@@ -146,7 +146,7 @@ def _multiset(rows, counts):
 
 
 
-def check_fullsize_properties(index, strs, cfg, d_reads, first_codes, L, max_classes=1 << 21):
+def check_fullsize_properties(index, strs, cfg, d_reads, first_codes, L, max_classes=1 << 21, strand_symmetry=True):
     """conservation, an oracle-checked sample (first_codes = codes of the first reads of d_reads), idempotence, linearity over a
     split, strand symmetry. Returns dict(called_frac, sample_sets)."""
     from oracle import oracle
@@ -178,6 +178,8 @@ def check_fullsize_properties(index, strs, cfg, d_reads, first_codes, L, max_cla
         merged[k] = merged.get(k, 0) + v
     assert merged == _multiset(a["rows"], a["counts"])
     del h1, h2
+    if not strand_symmetry:                               # (tolerated mismatches: SPEC 3's walk is directional, the two strands may differ)
+        return {"called_frac": float(a["reasons"][0]) / n, "sample_sets": sets}
     # strand symmetry
     rc = _run(index, cfg, _revcomp_packed(d_reads, L), L, max_classes)
     assert _multiset(rc["rows"], rc["counts"]) == _multiset(a["rows"], a["counts"])

@@ -362,3 +362,18 @@ def test_tolerated_mismatches_on_the_anchor_path(built, M, kw, monkeypatch):
     gpu = run_gpu(index, cfg, synth.pack_codes(codes[:8000]), lens[:8000], 150)
     assert gpu["kernels"][0].startswith("nb_align_general_kernel"), gpu["kernels"]
     assert_same(gpu, ox.align_strs(cfg, reads[:8000], n_threads=8), f"general kernel alone, num_mismatches {M}")
+
+
+def test_tolerated_mismatches_short_kmers_other_orientation(built):
+    """Found by scripts/fuzz_gpu.py (seed 9016): k = 12, 40-bp reads, num_mismatches = 2. After a base was passed over, the next STEP lookup
+    uses the CORRECTED k-mer; its position was then marked as settled for the other orientation's seed scan although the READ's own k-mer
+    there had never been looked up — with 12-mers that k-mer is in the table on the other strand often enough, and the other orientation's
+    coverage came out 0 instead of 17. Every read against the oracle (all four coverages)."""
+    from oracle import oracle
+    _, seqs, strs, _ = library_strings(1, 70, locus_len=600, seed=9016)
+    codes = synth.synth_reads(seqs, 200_000, 40, seed=9016, frac_random=0.6, err=0.004, n_rate=0.01)
+    cfg = engine.make_config(k=12, num_mismatches=2, score_threshold=20, score_filter=25)
+    gpu = run_gpu(engine.Index(strs, 12), cfg, synth.pack_codes(codes), None, 40, max_classes=1 << 20)
+    assert gpu["kernels"][0].startswith("nb_anchor_kernel"), gpu["kernels"]
+    blob, off = synth.reads_to_ascii(codes)
+    assert_same(gpu, oracle.OracleIndex(strs, 12).align(cfg, blob, off, n_threads=16), "k = 12, 40 bp, num_mismatches 2")

@@ -31,6 +31,20 @@ def test_c2_full_size_properties(built):
     assert 0.6 < res["called_frac"] < 0.8
 
 
+def test_c2_tolerated_mismatches_at_size(built):
+    """4 M x 150 bp vs 1 000 sequences with num_mismatches = 2 (anchor kernels passing over bases, their redo list on the general kernel):
+    conservation, an oracle-checked sample, idempotence and split linearity (no strand symmetry: SPEC 3's walk is directional once it may
+    pass over a base)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    _, seqs, _ = synth.synth_library(20, 50)
+    strs = [synth.codes_to_str(s) for s in seqs]
+    index = engine.Index(strs, 20)
+    d_reads, first = synth.synth_reads_packed_torch(seqs, 4_000_000, L, 21, dev, return_codes_of_first=20000)
+    res = check_fullsize_properties(index, strs, engine.make_config(num_mismatches=2), d_reads, first, L, max_classes=1 << 21, strand_symmetry=False)
+    assert 0.6 < res["called_frac"] < 0.85
+
+
 def test_c5_10k_seq_library_full_size(built):
     """BASELINE configs[4]: 10 000-sequence library (100 loci x 100 alleles; colour
     rows are 157 words: the TW = 4 kernel nb_align_se_kernel<3, 4, true>, classes wider than the two inline words of a colour
