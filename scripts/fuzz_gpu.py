@@ -28,8 +28,11 @@ def scenario(seed):
     _, seqs, strs, _ = library_strings(loci, alleles, locus_len=locus_len, seed=seed)
     err, n_rate, frac_random = float(rng.choice([0.0, 0.004, 0.01, 0.03])), float(rng.choice([0.0, 0.001, 0.01])), float(rng.choice([0.02, 0.1, 0.6]))
     kw = [dict(), dict(discard_multiple_matches=True), dict(strand_filter="fiveprime"), dict(score_percent=0.8, score_threshold=30), dict(strand_filter="threeprime", score_filter=40)][int(rng.integers(0, 5))]
-    if rng.random() < 0.15:
-        kw = dict(kw, num_mismatches=int(rng.integers(1, 3)))              # tolerated mismatches: the general kernel
+    force_mm = bool(os.environ.get("NB_FUZZ_MM"))                             # NB_FUZZ_MM=1: every scenario tolerates mismatches, k <= 23 (the anchor kernels' path)
+    if force_mm and k > 23:
+        k = int(rng.choice([12, 16, 20, 23]))
+    if force_mm or rng.random() < 0.15:
+        kw = dict(kw, num_mismatches=int(rng.integers(1, 5 if force_mm else 3)))   # tolerated mismatches: anchor kernels (k <= 23) or the general kernel
     if "score_threshold" not in kw:
         kw = dict(kw, score_threshold=max(k, 20), score_filter=max(k + 5, kw.get("score_filter", 25)))
     cfg = engine.make_config(k=k, **kw)
