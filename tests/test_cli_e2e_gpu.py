@@ -49,9 +49,11 @@ def expected_bulk(lib_path, reads, strand="unstranded"):
     return lib, ora
 
 
-def test_bulk_single_end(built, tmp_path):
-    lib_path, names, seqs, strs, lineage = make_library(tmp_path, max_hits_to_report=4)
-    codes = synth.synth_reads(seqs, 4000, 120, seed=3)
+@pytest.mark.parametrize("mm", [0, 2])
+def test_bulk_single_end(built, tmp_path, mm):
+    """(mm = the library's num_mismatches, /root/reference/nimble/types.py:15: 2 = the anchor kernels pass over bases, SPEC 3)"""
+    lib_path, names, seqs, strs, lineage = make_library(tmp_path, max_hits_to_report=4, num_mismatches=mm)
+    codes = synth.synth_reads(seqs, 4000, 120, seed=3, err=0.02)
     reads = [synth.codes_to_str(c) for c in codes]
     fq = tmp_path / "reads.fastq.gz"
     write_fastq(fq, [f"r{i}" for i in range(len(reads))], reads)
