@@ -175,7 +175,7 @@ __device__ __forceinline__ bool filter_maybe(const AnchorHead& h, uint64_t x, bo
   return valid && (h.pfilter[valid ? pf_word(hh, h.pf_wbits) : 0u] & m) == m;
 }
 
-template <int NR, int NW, bool PLDS, bool MATE>
+template <int NR, int NW, bool PLDS, bool MATE, bool MM>   // MM: num_mismatches > 0 (h.M): the code that passes over bases is compiled into its own instantiations
 __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const LaneTail* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ unsigned int s_reason[NB_NUM_REASONS];
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
         const int q = act ? (step ? pos - K + 1 : pos) : 0;           // k-mer position of this round's lookup
         uint64_t w; uint32_t nn; R.get32(q - (step ? 1 : 0), w, nn);  // (STEP: one base earlier, for the left-extension test; q >= 1 there)
         int pmax = -1;                                                 // the last corrected base inside the k-mer looked up (STEP with corrections)
-        if (h.M > 0 && __ballot(step && patches != 0ull)) {            // STEP continues from the CORRECTED k-mer: bases passed over take the text's value
+        if (MM && __ballot(step && patches != 0ull)) {            // STEP continues from the CORRECTED k-mer: bases passed over take the text's value
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const uint32_t e = (uint32_t)(patches >> (16 * i)) & 0xFFFFu;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
           mode = EXT;
         } else if (act) {
           if (pmax < 0) { const uint32_t j = div3((uint32_t)(q + 3 - res)); if ((int)(3u * j) == q + 3 - res) cover_set((int)j - 1, (int)j - 1); }     // (a looked-up position on the lattice; not if a corrected k-mer was looked up instead of the read's)
-          if (step && h.M > 0 && er && mm < h.M) fl |= F_SLOW;              // (the run ended for lack of room, not at a mismatch: whether SPEC 3 would pass over this base is not known here)
+          if (MM && step && er && mm < h.M) fl |= F_SLOW;              // (the run ended for lack of room, not at a mismatch: whether SPEC 3 would pass over this base is not known here)
           if (step) mode = pos > last ? DONE : SEEK;                          // the walk broke at base pos: seed scan from there (SPEC §3)
           else { pos += 3; mode = pos > last ? DONE : SEEK; }
         }
@@ -465,10 +465,10 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
           const int m = fm < fn ? fm : fn;
           const int room_left = maxsteps - steps;
           uint64_t rw = 0;                                                    // bit i: the text k-mer at run_t + steps + i is r_internal
-          if (h.M > 0) { const uint32_t tx = run_t + (uint32_t)steps; const uint32_t* rq = h.text_rint + (tx >> 5); rw = ((((uint64_t)rq[1]) << 32) | rq[0]) >> (tx & 31u); }
+          if (MM) { const uint32_t tx = run_t + (uint32_t)steps; const uint32_t* rq = h.text_rint + (tx >> 5); rw = ((((uint64_t)rq[1]) << 32) | rq[0]) >> (tx & 31u); }
           steps += m < room_left ? m : room_left;
           fin = (m < 32) || steps >= maxsteps;
-          if (h.M > 0 && m < 32 && m < room_left && mm < h.M && ((rw >> m) & 1ull)) {   // pass over the base at run_q + K + steps
+          if (MM && m < 32 && m < room_left && mm < h.M && ((rw >> m) & 1ull)) {   // pass over the base at run_q + K + steps
             cover_set((int)div3((uint32_t)(cv_from - res + 2 + 3)) - 1, (int)div3((uint32_t)(run_q + steps - res + 3)) - 1);
             cv_from = run_q + steps + K + 1;                                  // (the read's k-mers over that base are not the text's)
             { const int b_ = run_q + K + steps;                                 // the base passed over: remember what the text has there
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
     // then stops at a base that no sequence continues with (the sequencing error that killed the earlier seeds), at an N, or at its own
     // start. One comparison, one lookup (the left-extension mask of the k-mer at which the comparison stopped), one AND; if some sequence
     // does continue there, the read stays with the wave-per-read kernel. ----
-    if (h.M == 0 && __ballot((fl & F_REDO) == F_LEXT)) {                      // (with tolerated mismatches the left extension is the wave-per-read kernel's)
+    if (!MM && __ballot((fl & F_REDO) == F_LEXT)) {                      // (with tolerated mismatches the left extension is the wave-per-read kernel's)
       const bool le = (fl & F_REDO) == F_LEXT;
       int lm = 0; bool verify = false, solved = false;
       if (le) {
@@ -1015,9 +1015,9 @@ static int launch_scan_s(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail,
   }
 }
 
-template <int NR, int NW, bool PLDS, bool MATE>
-static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
-  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS, MATE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANCHOR_LDS_BUDGET));
+template <int NR, int NW, bool PLDS, bool MATE, bool MM>
+static int launch_anchor_m(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
+  NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nb_anchor_kernel<NR, NW, PLDS, MATE, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ANCHOR_LDS_BUDGET));
   long long blocks = c->n_cu;                                        // one workgroup per CU: the first level of the table is staged once per workgroup
   if (!PLDS && waves <= 8) blocks *= 2;                              // first level in global memory (large libraries: fabric-bound): 16 waves per CU
   if (const char* e = std::getenv("NB_ANCHOR_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) blocks = (long long)c->n_cu * v; }
@@ -1051,16 +1051,20 @@ static int launch_anchor_t(nb_ctx* c, const AnchorHead& h_in, const LaneTail* d_
     h.retry_rounds = 10;                                             // (short reads — c3, 91 bp — finish in fewer rounds than that: nothing handed over, nothing lost)
     if (const char* e = std::getenv("NB_ANCHOR_RETRY_ROUNDS")) h.retry_rounds = std::atoi(e);
   }
-  hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
+  hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE, MM>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
   NB_HIP(hipGetLastError());
   if (h.retry_out) {                                                 // second pass over the stragglers: same grid, workgroup b maps its own segment
     h.retry_in = h.retry_out; h.retry_out = nullptr;
-    hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
+    hipLaunchKernelGGL((nb_anchor_kernel<NR, NW, PLDS, MATE, MM>), dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), (size_t)lds, s, h, d_tail);
     NB_HIP(hipGetLastError());
     h.retry_in = nullptr;
   }
   return launch_scan_s<NR, MATE>(c, h, d_tail, blocks, waves, s);
   return NB_OK;
+}
+template <int NR, int NW, bool PLDS, bool MATE>
+static int launch_anchor_t(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, hipStream_t s) {
+  return h.M > 0 ? launch_anchor_m<NR, NW, PLDS, MATE, true>(c, h, d_tail, waves, lds, s) : launch_anchor_m<NR, NW, PLDS, MATE, false>(c, h, d_tail, waves, lds, s);
 }
 template <int NR, bool MATE>
 static int launch_anchor_n(nb_ctx* c, const AnchorHead& h, const LaneTail* d_tail, int waves, int64_t lds, bool plds, hipStream_t s) {

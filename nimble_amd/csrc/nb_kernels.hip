@@ -1436,7 +1436,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     rc = use_anchor ? launch_anchor(c, nr, ix, a, ll, s) : launch_lane(c, nr, ix, a, ll, s); if (rc != NB_OK) return rc;
     { char buf[240];
       if (use_anchor) {
-        char ak[80]; std::snprintf(ak, sizeof ak, "nb_anchor_kernel<%d, %d, %s, false>", nr > 5 ? 5 : nr, c->anchor_nw, anchor_pilots_in_lds(c, max_len) ? "true" : "false");
+        char ak[96]; std::snprintf(ak, sizeof ak, "nb_anchor_kernel<%d, %d, %s, false, %s>", nr > 5 ? 5 : nr, c->anchor_nw, anchor_pilots_in_lds(c, max_len) ? "true" : "false", cfg->num_mismatches > 0 ? "true" : "false");
         std::snprintf(buf, sizeof buf, "%s;%s%snb_anchor_scan_kernel<%d, %d, false>", ak, c->anchor_retry_ran ? ak : "", c->anchor_retry_ran ? ";" : "",   // (second launch: the stragglers' retry list)
                       nr > 5 ? 5 : nr, c->pf_s);
       }

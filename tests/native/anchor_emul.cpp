@@ -60,12 +60,12 @@ static void run_kernels(const AnchorHead& h_in, const LaneTail* tail, long long 
       blockIdx = dim3((unsigned)b);
       if (pass == 0) {
         h.retry_in = nullptr; h.retry_out = (retry && (b & 1)) ? retry->data() : nullptr; h.retry_counts = counts.data(); h.retry_lanes = 1;
-        nb_anchor_kernel<NR, NW, false, false>(h, tail);
+        (h.M > 0 ? nb_anchor_kernel<NR, NW, false, false, true>(h, tail) : nb_anchor_kernel<NR, NW, false, false, false>(h, tail));
         if (h.retry_out) g_retried += counts[(size_t)b];
       } else if (pass == 1) {
         if (!retry) continue;
         h.retry_out = nullptr; h.retry_in = retry->data(); h.retry_counts = counts.data();
-        nb_anchor_kernel<NR, NW, false, false>(h, tail);
+        (h.M > 0 ? nb_anchor_kernel<NR, NW, false, false, true>(h, tail) : nb_anchor_kernel<NR, NW, false, false, false>(h, tail));
       } else {
         // (the workgroup's copy of the LDS filter stage is a loop over all 1024 threads: with one lane per wave it is made here)
         if (h.lfilter) std::memcpy(s_dyn, h.lfilter, (size_t)SCAN_LF_WORDS * 4);

@@ -159,4 +159,4 @@ def test_bench_c3_per_cell(built):
     assert j["oracle_self_consistency_ok"] is True and pc is not None
     assert pc["reads"] == 4_000_000 and 0.5 * pc["reads"] < pc["called_rows"] <= pc["reads"]
     assert 0 < pc["output_rows"] <= pc["merged_rows"] <= pc["called_rows"] and pc["cells"] == 10_000
-    assert j["config"]["read_len"] == 91 and j["config"]["n_seqs"] == 1520 and j["roofline"]["kernel"] in ("nb_align_se_kernel<2, 1, false, true>", "nb_lane_kernel<2, 0>", "nb_anchor_kernel<2, 1, true, false>")
+    assert j["config"]["read_len"] == 91 and j["config"]["n_seqs"] == 1520 and j["roofline"]["kernel"] in ("nb_align_se_kernel<2, 1, false, true>", "nb_lane_kernel<2, 0>", "nb_anchor_kernel<2, 1, true, false, false>")
