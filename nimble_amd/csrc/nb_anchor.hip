@@ -16,7 +16,12 @@
 //   strand    (stream positions p = last, last - 3, ...) hits on the opposite strand. Positions inside verified runs cannot (runs never
 //             enter k-mers that occur on both strands); the remaining ones are looked up after the walk, eight in flight per lane.
 //   scan      a read none of whose probes is in the table at all is settled by nb_anchor_scan_kernel: every seed-scan position of both
-//             orientations, all lanes busy; nothing found = NO_HIT.
+//             orientations, behind the presence filter (one m-mer per tile of S positions: LDS stage, Bloom filter, exact lookup for what
+//             passes); nothing found = NO_HIT.
+//   retry     the few lanes that still walk when the rest of their wave is done hand their read over WITH the state of its walk; a second
+//             launch resumes those walks in waves that hold nothing else.
+//   mismatch  num_mismatches > 0 (MM): while the read follows the text a base that differs is passed over where the text k-mer is
+//             r_internal, and the walk goes on from the corrected k-mer (SPEC §3).
 //   redo      anything else — a k-mer on both strands, any opposite-strand hit, a first seed at or beyond L/5 (left extension), an
 //             anchor in a component wider than the sparse table's entries — puts the read on the redo list of the wave-per-read kernel.
 //   pairs     MATE form of both kernels + nb_anchor_pair_kernel: SPEC §4 for paired templates from the two mates' raw alignments.
