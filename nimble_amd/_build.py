@@ -39,17 +39,40 @@ def build(force=False, verbose=False):
             return LIB_PATH
         srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
         tmp = LIB_PATH + f".{os.getpid()}.tmp"
-        cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
-               "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC, "-o", tmp] + srcs + ["-lz"]
-        cmd[1:1] = os.environ.get("NB_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DNB_SE_WAVES_PER_EU=8 for tuning experiments
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
+        objdir = os.path.join(PKG_DIR, "build", f"obj.{os.getpid()}")
+        os.makedirs(objdir, exist_ok=True)
+        flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-pthread", "-ffp-contract=off",
+                 "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC]
+        flags[0:0] = os.environ.get("NB_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DNB_ANCHOR_PROF for tuning experiments
+        objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in srcs]
+
+        def compile_one(pair):
+            src, obj = pair
+            cmd = [_hipcc()] + flags + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+
         try:
+            # the translation units are independent (one hipcc each, side by side: the three kernel files take minutes), then one link
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1, 8)) as pool:
+                list(pool.map(compile_one, zip(srcs, objs)))
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-pthread", "-o", tmp] + objs + ["-lz"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
             os.replace(tmp, LIB_PATH)
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)
+            for o in objs:
+                if os.path.exists(o):
+                    os.remove(o)
+            try:
+                os.rmdir(objdir)
+            except OSError:
+                pass
     return LIB_PATH
 
 
