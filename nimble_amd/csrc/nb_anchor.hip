@@ -64,7 +64,7 @@ struct AnchorHead {
   // that hold nothing but long walks.
   uint32_t* retry_out; const uint32_t* retry_in; uint32_t* retry_counts; int retry_lanes, retry_rounds;
   uint32_t* retry_state; long long retry_seg;        // the walk of a straggler as it stood at the hand-over (RetryShape<NR, NW>::DW dwords per list entry); entries per workgroup segment
-  const uint32_t* pfilter; uint32_t pf_wbits;        // presence filter over the oriented k-mers of the table (nb_internal.h): 2^pf_wbits words
+  const uint32_t* pfilter; uint32_t pf_wbits;        // presence filter over the library's oriented m-mers (nb_internal.h): 2^pf_wbits words
   const uint32_t* lfilter;                           // its LDS-sized first stage (2^20 bits), or null (library too large for it to discriminate)
   const uint32_t* text_rint; int M;                  // num_mismatches > 0: r_internal bit of every text k-mer, the per-read budget of tolerated mismatches (SPEC 3)
 };
@@ -172,12 +172,6 @@ __device__ __forceinline__ LookKey anchor_lookup_key(const AnchorHead& h, const 
   if (!CHK(slot < h.ph.n_slots, 11)) slot = 0u;
   k.d = h.keys[slot] ^ pr.want;
   return k;
-}
-
-// presence filter (nb_internal.h): false = the k-mer is in the table on neither strand; true = maybe (the exact lookup decides)
-__device__ __forceinline__ bool filter_maybe(const AnchorHead& h, uint64_t x, bool valid) {
-  const uint32_t hh = pf_hash(x), m = pf_mask(hh);
-  return valid && (h.pfilter[valid ? pf_word(hh, h.pf_wbits) : 0u] & m) == m;
 }
 
 template <int NR, int NW, bool PLDS, bool MATE, bool MM>   // MM: num_mismatches > 0 (h.M): the code that passes over bases is compiled into its own instantiations

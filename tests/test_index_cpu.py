@@ -233,3 +233,18 @@ def test_presence_filter_has_no_false_negatives_and_few_false_positives(built, k
     fp = sum(ix.filter_maybe(x) for x in absent) / len(absent)
     assert len(absent) > 10000 and fp < 0.03, (len(absent), fp)
     assert ix.filter_maybe("ACGTN" * 8) is True                              # an N: nothing is known, the exact path decides
+
+
+def test_presence_filter_query_contract(built):
+    """nb_index_filter_maybe (include/nimble_amd.h): parameters with len = 0, NB_ERR_INVALID for a sequence shorter than m, 2 (None here) for an
+    index without the filter (k > 23: no anchor structures)."""
+    from nimble_amd._lib import NimbleError
+    _, _, strs, _ = library_strings(2, 4, locus_len=300, seed=5)
+    ix = engine.Index(strs, 20)
+    m, lds = ix.filter_params()
+    assert m == 13 and lds is True
+    with pytest.raises(NimbleError):
+        ix.filter_maybe("ACGTACGT")
+    assert ix.filter_maybe(strs[0][:m]) is True and ix.filter_maybe(strs[0][:60]) is True
+    wide = engine.Index(strs, 27)
+    assert wide.filter_params() is None and wide.filter_maybe("A" * 27) is None
