@@ -12,7 +12,7 @@ python bench.py --config $CFG --steps $STEPS --warmup 1 > "$OUT/bench.json" 2> "
 cut -c1-400 "$OUT/bench.json"
 Q="--config $CFG --warmup 1 --no-cpu-baseline --parity-sample 0"
 echo "== rocprofv3 kernel trace + stats =="
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps $STEPS $Q > "$OUT/trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py --steps $STEPS $Q --warmup 3 > "$OUT/trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
 for pass in "pmc_fetch FETCH_SIZE" "pmc_write WRITE_SIZE" "pmc_l2 TCC_HIT_sum TCC_MISS_sum"; do
   set -- $pass; name=$1; shift
   echo "== rocprofv3 PMC: $* =="
