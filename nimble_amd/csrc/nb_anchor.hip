@@ -65,6 +65,7 @@ struct AnchorHead {
   uint32_t* retry_out; const uint32_t* retry_in; uint32_t* retry_counts; int retry_lanes, retry_rounds;
   uint32_t* retry_state; long long retry_seg;        // the walk of a straggler as it stood at the hand-over (RetryShape<NR, NW>::DW dwords per list entry); entries per workgroup segment
   const uint32_t* pfilter; uint32_t pf_wbits;        // presence filter over the library's oriented m-mers (nb_internal.h): 2^pf_wbits words
+  int pf_s;                                          // its tile size S (m = k + 1 - S)
   const uint32_t* lfilter;                           // its LDS-sized first stage (2^20 bits), or null (library too large for it to discriminate)
   const uint32_t* text_rint; int M;                  // num_mismatches > 0: r_internal bit of every text k-mer, the per-read budget of tolerated mismatches (SPEC 3)
 };
@@ -560,9 +561,39 @@ __global__ __launch_bounds__(1024) void nb_anchor_kernel(AnchorHead h, const Lan
 #pragma unroll
         for (int wi = 0; wi < LW; ++wi) v |= todo[wi];
         return v != 0; };
-      // (tried: the presence filter of the scan kernel in front of these lookups. c2 3.52 ms against 3.21: the positions are few and per
-      //  lane, so the filter saves no request — one 4-byte load either way — and the second loop for the positions that pass costs more
-      //  than the shorter hash saves; profiles/r03_tuning_notes.md)
+      // Most of these positions are the k-mers over a sequencing error (the run before stopped there, the seed scan started after it):
+      // consecutive, and absent for one and the same reason. ONE m-mer of the presence filter (nb_internal.h) that lies inside all the
+      // k-mers at positions [p, p + S - 1] — the one that starts at p + S - 1, the first of them being the lowest unsettled point — clears
+      // their lattice points together (three at S = 8) with one 4-byte load and no hash of the table; what it cannot clear (an N inside,
+      // or an m-mer of the library: the tile right behind the error) takes the exact lookup below. One word of lattice points, S >= 4.
+      // Only where an exact lookup is expensive — first level of the hash in global memory (!PLDS: large libraries, c5 55.4 -> 53.7 ms); with
+      // the first level in LDS the extra round trip costs what the cheaper tests save (c2 2.89 against 2.84 ms; a filter over k-mers, one
+      // test per position, had been slower still: 3.52 against 3.21).
+      if (!PLDS && LW == 1 && h.pf_s >= 4 && !(h.dbg & 16)) {
+        const int S_ = h.pf_s, M_ = K + 1 - S_;
+        const uint64_t mmask_ = (1ull << (2 * M_)) - 1; const uint32_t nmm_ = (1u << M_) - 1u;
+        const uint64_t tile = S_ >= 8 ? 7ull : 3ull;                            // lattice points inside S consecutive positions, from the first
+        uint64_t exact = 0;
+        while (__ballot(todo[0] != 0)) {
+          constexpr int U = 4;
+          uint32_t fw[U], fm[U]; uint64_t bits[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const bool on = todo[0] != 0;
+            const int j = on ? __builtin_ctzll(todo[0]) : 0;
+            bits[u] = on ? (todo[0] & (tile << j)) : 0ull;
+            todo[0] &= ~bits[u];
+            const int q = res + 3 * j + S_ - 1;                                 // (q + M = p + k <= L: inside the read)
+            uint64_t w; uint32_t nn; R.get32(q, w, nn);
+            const bool clean = on && (nn & nmm_) == 0;
+            const uint32_t hh = pf_hash(w & mmask_);
+            fm[u] = clean ? pf_mask(hh) : 0u; fw[u] = h.pfilter[clean ? pf_word(hh, h.pf_wbits) : 0u];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) exact |= ((fw[u] & fm[u]) == fm[u]) ? bits[u] : 0ull;
+        }
+        todo[0] = exact;
+      }
       while (__ballot(any_todo())) {
         constexpr int U = 8;
         LookKey kk[U]; bool vv[U];
@@ -1096,7 +1127,7 @@ static AnchorHead make_head(const nb_ctx* c, int K, int W, const uint64_t* reads
   return AnchorHead{c->d_atable, c->d_akeys, c->d_ph_pilots, c->ph, K, c->d_text, c->d_sparse, c->text_len, reads, lens, max_len, nwb + (max_len + 63) / 64, nwb, n,
                     plds ? (int)(((int64_t)c->ph.n_groups + 15) / 16 * 16) : 0, 2 * (nwb + nwn) + 2,
                     (c->text_len + 15) / 16 + 4, (long long)ANCHOR_LEVELS * c->text_len * c->anchor_nw, W, mate_out,
-                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, c->d_pfilter, c->pf_wbits, c->d_lfilter, c->d_text_rint, num_mismatches};
+                    std::getenv("NB_ANCHOR_DBG") ? std::atoi(std::getenv("NB_ANCHOR_DBG")) : 0, c->d_scan_counts, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, c->d_pfilter, c->pf_wbits, c->pf_s, c->d_lfilter, c->d_text_rint, num_mismatches};
 }
 
 int launch_anchor(nb_ctx* c, int nr, const DevIndex& ix, const BatchArgs& a, const LaneLists& ll, hipStream_t s) {

@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
   LaneTail tail{ct, a, ll, W};
   std::vector<uint32_t> scan_counts((size_t)n_reads, 0);
   AnchorHead h{ix->atable.data(), ix->akeys.data(), ix->ph_pilots.data(), ix->ph, k, ix->text.data(), ix->sparse.data(), (long long)ix->text_len, reads.data(), lens.data(), max_len, stride, nwb,
-               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, ix->pfilter.data(), ix->pf_wbits, ix->lfilter.empty() ? nullptr : ix->lfilter.data(),
+               n_emul, 0, 2 * (nwb + nwn) + 2, (long long)ix->text.size(), (long long)ix->sparse.size(), W, nullptr, 0, scan_counts.data(), 64, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, ix->pfilter.data(), ix->pf_wbits, ix->pf_s, ix->lfilter.empty() ? nullptr : ix->lfilter.data(),
                ix->text_rint.data(), std::getenv("NB_EMUL_MM") ? std::atoi(std::getenv("NB_EMUL_MM")) : 0};   // NB_EMUL_MM = num_mismatches (the redo reads are then the general kernel's)
   std::vector<uint32_t> retry_list((size_t)n_reads * 64 + 64, 0);
   std::vector<uint32_t>* retry = std::getenv("NB_EMUL_RETRY") ? &retry_list : nullptr;
