@@ -29,7 +29,7 @@ def emul(tmp_path_factory):
     return exe
 
 
-def _run(emul, tmp_path, strs, k, reads, max_len, cfg, max_redo_frac):
+def _run(emul, tmp_path, strs, k, reads, max_len, cfg, max_redo_frac, thorough=True):
     from oracle import oracle
     words, lens = engine.pack_reads(reads, max_len)
     inp, out = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
@@ -43,7 +43,7 @@ def _run(emul, tmp_path, strs, k, reads, max_len, cfg, max_redo_frac):
     ora = oracle.OracleIndex(strs, k).align_strs(cfg, reads, n_threads=4)
     # one pass of nb_anchor_kernel, and with every other read handed to its second pass (the stragglers' retry list, with the state of the
     # walk) before its first round, after two rounds and after five
-    for retry in (0, 2, 5, None):
+    for retry in ((0, 2, 5, None) if thorough else (2, None)):
         got, log = _emulate(emul, inp, out, retry)
         _compare(got, ora, max_redo_frac, log)
         retried = int(log.split("retried ")[1].split(",")[0])
@@ -51,10 +51,10 @@ def _run(emul, tmp_path, strs, k, reads, max_len, cfg, max_redo_frac):
             assert (retried > 0) == (retry is not None and len(reads) > 50), log
     # tolerated mismatches (num_mismatches 1 and 3): the walk passes over a base while it follows the text and goes on from the corrected
     # k-mer; what the kernels finish themselves must equal the oracle run with the same budget (first pass, and resumed after two rounds)
-    for mm in (1, 3):
+    for mm in ((1, 3) if thorough else (2,)):
         cfg_m = engine.make_config(**{**_cfg_kwargs(cfg), "num_mismatches": mm})
         ora_m = oracle.OracleIndex(strs, k).align_strs(cfg_m, reads, n_threads=4)
-        for retry in (None, 2):
+        for retry in ((None, 2) if thorough else (2,)):
             got_m, log_m = _emulate(emul, inp, out, retry, mm=mm)
             _compare(got_m, ora_m, min(1.0, max_redo_frac + 0.15), log_m)
     return got, ora, log
@@ -146,7 +146,7 @@ def test_awkward_libraries(built, emul, tmp_path, seed, k_over):
     from tests.helpers import weird_scenario
     k, strs, reads, max_len = weird_scenario(seed, k_over)
     try:
-        _run(emul, tmp_path, strs, k, reads, max_len, engine.make_config(k=k, score_threshold=k, score_filter=k + 2), 1.0)
+        _run(emul, tmp_path, strs, k, reads, max_len, engine.make_config(k=k, score_threshold=k, score_filter=k + 2), 1.0, thorough=False)
     except AssertionError as e:
         if "no anchor structures" in str(e):
             pytest.skip("library without anchor structures (most of it on both strands / wide components)")
