@@ -1388,7 +1388,7 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   const int lmax = max_len > mate_max_len ? max_len : mate_max_len;
   const int positions = lmax - c->K + 1;
   if (positions > NB_MAX_POSITIONS) { set_error("nb_align_batch: read longer than NB_MAX_POSITIONS + k - 1"); return NB_ERR_UNSUPPORTED; }
-  if (c->W > 64 * 4) { set_error("nb_align_batch: the library needs more than 256 words per class row (about 16 000 sequences)"); return NB_ERR_UNSUPPORTED; }
+  if (c->W > 64 * 16) { set_error("nb_align_batch: the library needs more than 1 024 words per class row (about 65 000 sequences)"); return NB_ERR_UNSUPPORTED; }
   if (n == 0) return NB_OK;
   NB_HIP(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1449,12 +1449,12 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     b.out_class = a.out_class ? c->d_redo_out : nullptr; b.out_info = a.out_info ? c->d_redo_out + c->lists_cap : nullptr;
     b.out_cov = a.out_cov ? reinterpret_cast<uint64_t*>(c->d_redo_out + 2 * c->lists_cap) : nullptr;
     if (cfg->num_mismatches > 0) {                                            // the redo reads of a run with tolerated mismatches: the LDS-staged mapper
-      if (c->compact) rc = (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, false, ix, b, s) : dispatch_general<4, true>(c, nr, positions, false, ix, b, s);
-      else rc = (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, false, ix, b, s) : dispatch_general<4, false>(c, nr, positions, false, ix, b, s);
+      if (c->compact) rc = (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, false, ix, b, s) : (c->W <= 256 ? dispatch_general<4, true>(c, nr, positions, false, ix, b, s) : dispatch_general<16, true>(c, nr, positions, false, ix, b, s));
+      else rc = (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, false, ix, b, s) : (c->W <= 256 ? dispatch_general<4, false>(c, nr, positions, false, ix, b, s) : dispatch_general<16, false>(c, nr, positions, false, ix, b, s));
       c->last_kernels = std::string(buf_names) + ";" + c->last_kernels;
     } else
-    if (c->compact) rc = (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, b, s) : dispatch_se<4, true>(c, nr, positions, ix, b, s);
-    else rc = (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, b, s) : dispatch_se<4, false>(c, nr, positions, ix, b, s);   // (anchors next to the wide table)
+    if (c->compact) rc = (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, b, s) : (c->W <= 256 ? dispatch_se<4, true>(c, nr, positions, ix, b, s) : dispatch_se<16, true>(c, nr, positions, ix, b, s));
+    else rc = (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, b, s) : (c->W <= 256 ? dispatch_se<4, false>(c, nr, positions, ix, b, s) : dispatch_se<16, false>(c, nr, positions, ix, b, s));   // (anchors next to the wide table)
     if (rc != NB_OK) return rc;
     BatchArgs sc = a; sc.n = c->lists_cap;
     return launch_lane_scatter(c, sc, ll, c->d_redo_out, s);
@@ -1496,8 +1496,8 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
     b.out_class = a.out_class ? c->d_redo_out : nullptr; b.out_info = a.out_info ? c->d_redo_out + c->lists_cap : nullptr;
     b.out_cov = a.out_cov ? reinterpret_cast<uint64_t*>(c->d_redo_out + 2 * c->lists_cap) : nullptr;
     const bool exact_redo = cfg->num_mismatches == 0;
-    if (c->compact) rc = (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, exact_redo, ix, b, s) : dispatch_general<4, true>(c, nr, positions, exact_redo, ix, b, s);
-    else rc = (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, exact_redo, ix, b, s) : dispatch_general<4, false>(c, nr, positions, exact_redo, ix, b, s);
+    if (c->compact) rc = (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, exact_redo, ix, b, s) : (c->W <= 256 ? dispatch_general<4, true>(c, nr, positions, exact_redo, ix, b, s) : dispatch_general<16, true>(c, nr, positions, exact_redo, ix, b, s));
+    else rc = (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, exact_redo, ix, b, s) : (c->W <= 256 ? dispatch_general<4, false>(c, nr, positions, exact_redo, ix, b, s) : dispatch_general<16, false>(c, nr, positions, exact_redo, ix, b, s));
     if (rc != NB_OK) return rc;
     c->last_kernels = "nb_anchor_kernel<mates>;nb_anchor_scan_kernel<mates>;nb_anchor_pair_kernel;" + c->last_kernels;
     BatchArgs sc = a; sc.n = c->lists_cap;
@@ -1506,11 +1506,11 @@ int32_t nb_align_batch(nb_ctx* c, const nb_config* cfg, const uint64_t* d_reads,
   if (d_mates || cfg->num_mismatches > 0)   // pairs and tolerated mismatches take the general (eager, LDS-staged) kernel
   {
     const bool exact = cfg->num_mismatches == 0;
-    if (c->compact) return (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, exact, ix, a, s) : dispatch_general<4, true>(c, nr, positions, exact, ix, a, s);
-    return (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, exact, ix, a, s) : dispatch_general<4, false>(c, nr, positions, exact, ix, a, s);
+    if (c->compact) return (c->W <= 64) ? dispatch_general<1, true>(c, nr, positions, exact, ix, a, s) : (c->W <= 256 ? dispatch_general<4, true>(c, nr, positions, exact, ix, a, s) : dispatch_general<16, true>(c, nr, positions, exact, ix, a, s));
+    return (c->W <= 64) ? dispatch_general<1, false>(c, nr, positions, exact, ix, a, s) : (c->W <= 256 ? dispatch_general<4, false>(c, nr, positions, exact, ix, a, s) : dispatch_general<16, false>(c, nr, positions, exact, ix, a, s));
   }
-  if (c->compact) return (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, a, s) : dispatch_se<4, true>(c, nr, positions, ix, a, s);
-  return (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, a, s) : dispatch_se<4, false>(c, nr, positions, ix, a, s);
+  if (c->compact) return (c->W <= 64) ? dispatch_se<1, true>(c, nr, positions, ix, a, s) : (c->W <= 256 ? dispatch_se<4, true>(c, nr, positions, ix, a, s) : dispatch_se<16, true>(c, nr, positions, ix, a, s));
+  return (c->W <= 64) ? dispatch_se<1, false>(c, nr, positions, ix, a, s) : (c->W <= 256 ? dispatch_se<4, false>(c, nr, positions, ix, a, s) : dispatch_se<16, false>(c, nr, positions, ix, a, s));
 }
 
 // Read-backs go through a stream of their own (non-blocking: none of the legacy null stream's implicit synchronisation with every other
@@ -1705,8 +1705,8 @@ const char* nb_kernel_name(int32_t max_len, int32_t k, int32_t n_seqs, int32_t p
   static thread_local char buf[96];
   const int positions = max_len - k + 1; const int nr = positions < 1 ? 1 : (positions + 63) / 64; const int W = (n_seqs + 63) / 64;
   const char* ct = (k <= COMPACT_MAX_K && !(std::getenv("NB_TABLE") && std::string(std::getenv("NB_TABLE")) == "wide") && n_seqs <= 2000) ? "true" : "false";   // (a guess from the shape: the real choice is by table size, nb_index.cpp; nb_last_kernel_names(ctx) is exact)
-  if (paired) std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d, %d, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? 2 : 1, ct);
-  else std::snprintf(buf, sizeof buf, "nb_align_se_kernel<%d, %d, %s, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : 4, use_tri(positions, k) ? "true" : "false", ct);
+  if (paired) std::snprintf(buf, sizeof buf, "nb_align_general_kernel<%d, %d, %d, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : (W <= 256 ? 4 : 16), use_tri(positions, k) ? 2 : 1, ct);
+  else std::snprintf(buf, sizeof buf, "nb_align_se_kernel<%d, %d, %s, %s>", use_tri(positions, k) ? 3 : (nr > 5 ? 5 : nr), W <= 64 ? 1 : (W <= 256 ? 4 : 16), use_tri(positions, k) ? "true" : "false", ct);
   return buf;
 }
 

@@ -123,3 +123,33 @@ def test_pairs_exact_mode_front_ends(built, l1, l2, kw):
     c1, c2 = synth_pairs(seqs, 2500, l1, l2, seed=9, frag=320 if max(l1, l2) < 300 else 400)
     gpu, ora = _both(strs, engine.make_config(**kw), c1, c2)
     assert_same(gpu, ora, f"pairs exact {l1}/{l2} {kw}")
+
+
+def test_library_beyond_16k_sequences(built):
+    """21 000 sequences (300 loci x 70 alleles): class rows of 329 words (600 in the engine's internal numbering, where every locus starts at
+    a word boundary) — beyond the 256 words four-words-per-lane kernels hold; the wave-per-read kernels run with sixteen words per lane
+    (`nb_align_se_kernel<., 16, ., .>`, `nb_align_general_kernel<., 16, ., .>`). Single-end through the anchor path (its redo list on the
+    sixteen-word kernel), with tolerated mismatches, and paired on the general kernel alone; every read against the oracle."""
+    from oracle import oracle
+    from tests.helpers import library_strings
+    _, seqs, strs, _ = library_strings(300, 70, locus_len=300, seed=5150)
+    index = engine.Index(strs, 20)
+    assert index.stats()["words_internal"] > 256
+    ox = oracle.OracleIndex(strs, 20)
+    codes = synth.synth_reads(seqs, 30000, 150, seed=8, err=0.01, n_rate=0.002)
+    blob, off = synth.reads_to_ascii(codes)
+    for cfg in (engine.make_config(), engine.make_config(num_mismatches=2, discard_multiple_matches=True)):
+        gpu = run_gpu(index, cfg, synth.pack_codes(codes), None, 150, max_classes=1 << 18)
+        assert any("16" in n.split("<")[1].split(",")[1] for n in gpu["kernels"] if n.startswith(("nb_align_se_kernel", "nb_align_general_kernel"))), gpu["kernels"]
+        assert_same(gpu, ox.align(cfg, blob, off, n_threads=16), f"21 000 sequences, {cfg.num_mismatches} mismatches")
+    import os
+    os.environ["NB_ANCHOR"] = "0"; os.environ["NB_LANE"] = "0"
+    try:
+        c1, c2 = synth_pairs(seqs, 6000, 120, 91, seed=4)
+        cfg = engine.make_config(intersect_level=1)
+        gpu = run_gpu(index, cfg, synth.pack_codes(c1), None, 120, max_classes=1 << 18, mate_words=synth.pack_codes(c2), mate_max_len=91)
+        assert gpu["kernels"][0].startswith("nb_align_general_kernel") and ", 16," in gpu["kernels"][0], gpu["kernels"]
+        b1, o1 = synth.reads_to_ascii(c1); b2, o2 = synth.reads_to_ascii(c2)
+        assert_same(gpu, ox.align(cfg, b1, o1, b2, o2, n_threads=16), "21 000 sequences, pairs on the general kernel")
+    finally:
+        os.environ.pop("NB_ANCHOR", None); os.environ.pop("NB_LANE", None)
