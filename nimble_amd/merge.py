@@ -98,6 +98,19 @@ def row_digests_t(rows_t):
     return torch.stack([(x1 * nz).sum(dim=1), (x2 * nz).sum(dim=1)], dim=1)
 
 
+def _to_host(t):
+    """Device tensor -> numpy array through a PINNED host buffer of torch's caching host allocator. A plain `.cpu()` lands in pageable memory,
+    which the HIP runtime registers with the GPU for the length of the copy when it is larger than a staging buffer; when numpy frees (unmaps)
+    such an array the driver's MMU notifier evicts and restores every queue of the process: the GPU then starts nothing for 25-35 ms
+    (profiles/r03_dist_rehearsal.md: the 11 MB of merged rows, freed inside the job). Pinned blocks are never unmapped while the process runs."""
+    import torch
+    if t.device.type != "cuda":
+        return t.numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t)
+    return h.numpy()                     # (the array keeps the tensor, and with it the pinned block, alive)
+
+
 def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, compute_device=None):
     """rows [n, W] uint64 / counts [n] int64 of THIS rank -> (global_rows, global_counts).
     `device` is where the collective buffers live (the GPU under RCCL, the CPU under gloo), `compute_device` where the tensor ops run
@@ -114,8 +127,8 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
     if not on_device:
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         counts = np.ascontiguousarray(counts, dtype=np.int64)
-    if world == 1:
-        return (rows.cpu().numpy().view(np.uint64), counts.cpu().numpy()) if on_device else (rows, counts)
+    if world == 1 and os.environ.get("NB_MERGE_REHEARSE") != "1":       # (NB_MERGE_REHEARSE=1: the collectives below with a group of one rank)
+        return (_to_host(rows).view(np.uint64), _to_host(counts)) if on_device else (rows, counts)
     comm = device if device is not None else torch.device("cpu")
     dev = compute_device if compute_device is not None else comm
     n, W = rows.shape
@@ -145,7 +158,7 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
         dense.index_add_(0, my_gid, counts.to(dev) if on_device else torch.from_numpy(counts).to(dev))
     dense_c = dense.to(comm)
     dist.all_reduce(dense_c, op=dist.ReduceOp.SUM, group=group)
-    global_counts = dense_c.cpu().numpy()
+    global_counts = _to_host(dense_c)
     # 3. rows to the root: each distinct row once, from its owner (the lowest rank that holds the digest); the root's own rows stay put
     owner = torch.full((G,), world, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, owner_of, reduce="amin", include_self=True)
     mine = owner[my_gid] == rank if n else torch.zeros(0, dtype=torch.bool, device=dev)
@@ -164,7 +177,7 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
             g[torch.nonzero(owner == r).flatten()] = block.to(dev)
         if not bool((row_digests_t(g) == uniq).all()):                      # every row must hash to the digest it was filed under
             raise RuntimeError("class dictionary agreement: a received row does not match its digest")
-        global_rows = g.cpu().numpy().view(np.uint64).reshape(G, W)
+        global_rows = _to_host(g).view(np.uint64).reshape(G, W)
     elif sel.numel():
         dist.send(rows_t[sel].contiguous().to(comm), dst=root, group=group)
     return global_rows, global_counts
