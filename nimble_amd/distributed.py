@@ -8,6 +8,8 @@ threads do when they merge their per-thread {feature set -> count} maps at the e
 (process boundary at /root/reference/nimble/__main__.py:195-198)."""
 import numpy as np
 
+from .merge import _to_host       # device -> host through pinned blocks (see there: freed pageable arrays stall the GPU)
+
 
 def unique_rows(rows):
     """(unique rows in lexicographic order (word 0 most significant), inverse index) of a [n, W] uint64 array.
@@ -62,7 +64,7 @@ def _agree(R, use_hash=True):
         glob = R[first]
         if bool((glob[inv] == R).all()):
             return glob, inv
-    g, i = unique_rows(R.cpu().numpy().view(np.uint64))
+    g, i = unique_rows(_to_host(R).view(np.uint64))
     return torch.from_numpy(g.view(np.int64)).to(R.device), torch.from_numpy(i).to(R.device)
 
 
@@ -99,4 +101,4 @@ def reduce_class_counts(rows, counts, device=None, group=None):
     if sizes[rank]:
         dense.index_add_(0, inv[lo:lo + sizes[rank]], torch.from_numpy(counts).to(dev))
     dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
-    return glob.cpu().numpy().view(np.uint64).reshape(-1, W), dense.cpu().numpy()[:glob.shape[0]]
+    return _to_host(glob).view(np.uint64).reshape(-1, W), _to_host(dense)[:glob.shape[0]]

@@ -174,9 +174,10 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
                 continue
             block = torch.empty((per_owner[r], W), dtype=torch.int64, device=comm)
             dist.recv(block, src=r, group=group)
-            g[torch.nonzero(owner == r).flatten()] = block.to(dev)
-        if not bool((row_digests_t(g) == uniq).all()):                      # every row must hash to the digest it was filed under
-            raise RuntimeError("class dictionary agreement: a received row does not match its digest")
+            block, at = block.to(dev), torch.nonzero(owner == r).flatten()
+            if not bool((row_digests_t(block) == uniq[at]).all()):         # every received row must hash to the digest it is filed under
+                raise RuntimeError(f"class dictionary agreement: a row received from rank {r} does not match its digest")
+            g[at] = block
         global_rows = _to_host(g).view(np.uint64).reshape(G, W)
     elif sel.numel():
         dist.send(rows_t[sel].contiguous().to(comm), dst=root, group=group)
