@@ -98,6 +98,23 @@ def row_digests_t(rows_t):
     return torch.stack([(x1 * nz).sum(dim=1), (x2 * nz).sum(dim=1)], dim=1)
 
 
+class _StageClock:
+    def __init__(self, dev):
+        import time
+        self.dev, self.t, self.parts, self.time = dev, time.perf_counter(), [], time
+
+    def __call__(self, label, last=False):
+        import sys
+        import torch
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        now = self.time.perf_counter()
+        self.parts.append(f"{label} {(now - self.t) * 1e3:.2f}")
+        self.t = now
+        if last:
+            print("[merge] ms: " + ", ".join(self.parts), file=sys.stderr)
+
+
 def _to_host(t):
     """Device tensor -> numpy array through a PINNED host buffer of torch's caching host allocator. A plain `.cpu()` lands in pageable memory,
     which the HIP runtime registers with the GPU for the length of the copy when it is larger than a staging buffer; when numpy frees (unmaps)
@@ -132,12 +149,15 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
     comm = device if device is not None else torch.device("cpu")
     dev = compute_device if compute_device is not None else comm
     n, W = rows.shape
+    clock = _StageClock(dev) if os.environ.get("NB_MERGE_TIMING") == "1" else None      # stage clock on stderr (synchronises between stages)
     rows_t = rows.to(dev) if on_device else torch.from_numpy(rows.view(np.int64)).to(dev)
     dig = row_digests_t(rows_t) if n else torch.zeros((0, 2), dtype=torch.int64, device=dev)
+    if clock: clock("digests")
     # 1. dictionary agreement by digest: 16 bytes per class
     parts = _all_gather_var(dig.to(comm), group, comm)
     sizes = [int(p.shape[0]) for p in parts]
     allv = torch.cat(parts, dim=0).to(dev)
+    if clock: clock("all-gather of digests")
     owner_of = torch.repeat_interleave(torch.arange(world, dtype=torch.int64, device=dev), torch.tensor(sizes, dtype=torch.int64, device=dev))
     if allv.shape[0] == 0:
         return (np.zeros((0, W), dtype=np.uint64) if rank == root else None), np.zeros(0, dtype=np.int64)
@@ -150,6 +170,7 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
     else:
         uniq = torch.stack([u1, first2], dim=1)
     G = int(uniq.shape[0])
+    if clock: clock("unique")
     lo = sum(sizes[:rank])
     my_gid = inv[lo:lo + n]
     # 2. ONE all-reduce of the dense count vector
@@ -159,12 +180,14 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
     dense_c = dense.to(comm)
     dist.all_reduce(dense_c, op=dist.ReduceOp.SUM, group=group)
     global_counts = _to_host(dense_c)
+    if clock: clock("dense vector, all-reduce, counts to the host")
     # 3. rows to the root: each distinct row once, from its owner (the lowest rank that holds the digest); the root's own rows stay put
     owner = torch.full((G,), world, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, owner_of, reduce="amin", include_self=True)
     mine = owner[my_gid] == rank if n else torch.zeros(0, dtype=torch.bool, device=dev)
     sel = torch.nonzero(mine).flatten()
     sel = sel[torch.argsort(my_gid[sel])]                                   # in ascending global id: the order the root files them in
     global_rows = None
+    if clock: clock("owners")
     if rank == root:
         g = torch.zeros((G, W), dtype=torch.int64, device=dev)
         g[my_gid[sel]] = rows_t[sel]
@@ -181,6 +204,7 @@ def reduce_class_counts_hashed(rows, counts, device=None, group=None, root=0, co
         global_rows = _to_host(g).view(np.uint64).reshape(G, W)
     elif sel.numel():
         dist.send(rows_t[sel].contiguous().to(comm), dst=root, group=group)
+    if clock: clock("rows to the root", last=True)
     return global_rows, global_counts
 
 
