@@ -74,6 +74,11 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
   if (k < 2 || k > NB_MAX_K) { set_error("nb_index_build: k must be in 2..31"); return NB_ERR_INVALID; }
   const uint64_t mask = kmer_mask(k);
   const int top = 2 * (k - 1);
+  const bool dbg = std::getenv("NB_INDEX_DEBUG") != nullptr;             // stage clock on stderr
+  auto tick = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (dbg) { const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[nb_index] %-28s %.2f s\n", what, std::chrono::duration<double>(now - tick).count()); tick = now; }
+  };
 
   // 1. occurrences
   int64_t total = 0;
@@ -96,8 +101,10 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
   }
   if (occ.empty()) { set_error("nb_index_build: library has no k-mer of length k"); return NB_ERR_INVALID; }
   const int threads = index_threads();
+  lap("occurrences");
   parallel_sort(occ, threads, [](const Occ& a, const Occ& b) { return a.kmer != b.kmer ? a.kmer < b.kmer : a.seq < b.seq; });
 
+  lap("occurrences sorted");
   // 2. group by k-mer: merged exts, member list; intern member lists into temp colour ids
   std::vector<KRec> recs;
   std::vector<uint32_t> pool;                 // concatenated member lists of distinct colours
@@ -129,6 +136,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
     i = j;
   }
   std::vector<Occ>().swap(occ);
+  lap("grouped by k-mer, classes");
   const uint32_t n_col = (uint32_t)(col_off.size() - 1);
   if (n_col > MAX_COLOURS) { set_error("nb_index_build: more than 2^22-1 equivalence classes"); return NB_ERR_UNSUPPORTED; }
 
@@ -340,12 +348,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
   //     per ~3 k-mers in global memory for the libraries whose table is far beyond the L2s anyway (anchor kernel only: one more L2-resident
   //     load per lookup, but ~25 lookups per read instead of one per position).
   const char* ph_env = std::getenv("NB_PH");
-  const bool dbg = std::getenv("NB_INDEX_DEBUG") != nullptr;
-  auto tick = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) {
-    if (dbg) { const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[nb_index] %-28s %.2f s\n", what, std::chrono::duration<double>(now - tick).count()); tick = now; }
-  };
-  lap("up to the k-mer table");
+  lap("layouts, k-mer table");
   if (dbg) std::fprintf(stderr, "[nb_index] k=%d max_comp_words=%d max_desc_nw=%d n_canon=%lld\n", k, ix->max_comp_words, ix->max_desc_nw, (long long)n_canon);
   if (k <= COMPACT_MAX_K && !(ph_env && ph_env[0] == '0')) {
     static const uint32_t PMULS[2] = {0x9E3779B1u, 0x85EBCA77u};
@@ -508,9 +511,10 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       }
       lap("anchors");
       // level 0: the class of the k-mer at every text position as NW words from the first word of its sequence's component
-      ix->sparse.assign((size_t)ANCHOR_LEVELS * (size_t)T * (size_t)NW, 0ull);
-      lap("  sparse: allocate + zero");
+      ix->sparse.resize((size_t)ANCHOR_LEVELS * (size_t)T * (size_t)NW);      // (uninitialised: level 0 is zeroed range by range below, the levels above write every word)
+      lap("  sparse: allocate");
       parallel_ranges((size_t)T, threads, [&](size_t lo, size_t hi) {
+        std::memset(ix->sparse.data() + lo * (size_t)NW, 0, (hi - lo) * (size_t)NW * 8);
         for (size_t j = lo; j < hi; ++j) {
           const uint32_t i = cidx[j];
           if (i == NONE) continue;
@@ -570,7 +574,7 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
           if ((double)set > LF_MAX_FILL * (double)((int64_t)1 << LF_BITS_LOG2)) std::vector<uint32_t>().swap(ix->lfilter); }
         lap("presence filter");
       }
-      if (!fits) { std::vector<uint32_t>().swap(ix->text_rint); std::vector<uint32_t>().swap(ix->lfilter); std::vector<uint32_t>().swap(ix->pfilter); std::vector<uint32_t>().swap(ix->akeys); std::vector<AEntry>().swap(ix->atable); std::vector<uint64_t>().swap(ix->sparse); std::vector<uint32_t>().swap(ix->text); }
+      if (!fits) { std::vector<uint32_t>().swap(ix->text_rint); std::vector<uint32_t>().swap(ix->lfilter); std::vector<uint32_t>().swap(ix->pfilter); std::vector<uint32_t>().swap(ix->akeys); std::vector<AEntry>().swap(ix->atable); WordsNoInit().swap(ix->sparse); std::vector<uint32_t>().swap(ix->text); }
     }
   }
   ix->n_canonical = n_canon;
