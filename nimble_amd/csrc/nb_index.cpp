@@ -476,14 +476,16 @@ int build_host_index(int n_seqs, const char* const* seqs, const int64_t* lens, i
       // r_internal (SPEC 2) of the k-mer that starts at every text position, as it is oriented there: what lets the walk tolerate a
       // mismatch (num_mismatches > 0) while it follows the text — the unique right extension of such a k-mer IS the text's next base
       ix->text_rint.assign((size_t)((T + 31) / 32 + 2), 0u);
-      for (int64_t j = 0; j < T; ++j) {
-        const uint32_t a = cidx[(size_t)j];
-        if (a == NONE) continue;
-        uint64_t x = 0;
-        for (int t = 0; t < k; ++t) x |= (uint64_t)code[(size_t)j + (size_t)t] << (2 * t);
-        const uint32_t pay = canons[a].pay[x != canons[a].key ? 1 : 0];
-        if (pay != PAY_ABSENT && ((pay >> 8) & 1u)) ix->text_rint[(size_t)(j >> 5)] |= 1u << (j & 31);
-      }
+      parallel_ranges((size_t)((T + 31) / 32), threads, [&](size_t wlo, size_t whi) {          // (a range of whole words per thread)
+        for (int64_t j = (int64_t)wlo * 32; j < std::min<int64_t>(T, (int64_t)whi * 32); ++j) {
+          const uint32_t a = cidx[(size_t)j];
+          if (a == NONE) continue;
+          uint64_t x = 0;
+          for (int t = 0; t < k; ++t) x |= (uint64_t)code[(size_t)j + (size_t)t] << (2 * t);
+          const uint32_t pay = canons[a].pay[x != canons[a].key ? 1 : 0];
+          if (pay != PAY_ABSENT && ((pay >> 8) & 1u)) ix->text_rint[(size_t)(j >> 5)] |= 1u << (j & 31);
+        }
+      });
       std::vector<uint8_t> lroom((size_t)T + 1, 0);          // the same towards the left (SPEC 3's left extension from the first seed)
       for (int64_t j = 1; j < T; ++j) {
         const uint32_t a = cidx[(size_t)j], b = cidx[(size_t)j - 1];
